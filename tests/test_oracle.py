@@ -1,0 +1,375 @@
+"""CPU tests of the oracle (oracle/icp_oracle.c) -- the checker itself.
+
+Pinned parts: Kabsch vs tests/golden/kabsch_golden.npz (outputs of the
+reference's rigid_transform_3D.py).  Everything else is "parity unpinned"
+(reference C++ needs OpenCV, absent here): checked against independent numpy
+restatements of the cited lines and hand-computable known answers.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from icp_slam_prototype_amd import synth
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def np_dist_matrix(src, tgt):
+    """Independent numpy restatement of icp.cpp:606-620 for all pairs."""
+    dx = (src[0][:, None] - tgt[0][None, :]).astype(np.float32)
+    dy = (src[1][:, None] - tgt[1][None, :]).astype(np.float32)
+    dz = (src[2][:, None] - tgt[2][None, :]).astype(np.float32)
+    s = (dx.astype(np.float64) ** 2 + dy.astype(np.float64) ** 2) + dz.astype(np.float64) ** 2
+    return np.sqrt(s.astype(np.float32))  # float32 sqrt is correctly rounded in numpy
+
+
+# ---------------------------------------------------------------- distance --
+def test_distance_known_answers(oracle):
+    assert oracle.distance((3, 4, 0), (0, 0, 0)) == np.float32(5.0)
+    assert oracle.distance((1, 2, 2), (0, 0, 0)) == np.float32(3.0)
+    assert oracle.distance((5, 5, 5), (5, 5, 5)) == np.float32(0.0)
+    # symmetric
+    assert oracle.distance((0.1, 0.2, 0.3), (1.5, -2.0, 7.0)) == oracle.distance((1.5, -2.0, 7.0), (0.1, 0.2, 0.3))
+
+
+def test_distance_double_path_differs_from_float_path(oracle):
+    """The reference squares/adds in double (pow(float,int) -> double) and rounds
+    once; a float-only evaluation differs on a measurable fraction of inputs, so
+    this test would catch a restatement that used float arithmetic."""
+    rng = np.random.default_rng(0)
+    a = rng.uniform(-3, 3, (3, 4000)).astype(np.float32)
+    b = rng.uniform(-3, 3, (3, 4000)).astype(np.float32)
+    d = a - b
+    ref = np.sqrt(((d[0].astype(np.float64) ** 2 + d[1].astype(np.float64) ** 2) + d[2].astype(np.float64) ** 2).astype(np.float32))
+    flt = np.sqrt((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2])
+    got = np.array([oracle.distance(a[:, i], b[:, i]) for i in range(a.shape[1])], np.float32)
+    assert np.array_equal(got, ref)
+    assert (flt != ref).sum() > 10  # the distinction is observable
+
+
+def test_pow_promotion_is_double():
+    """C++11 [c.math]: pow(float,int) is evaluated in double whichever overload
+    set is visible.  Which sqrt overload the
+    reference's unqualified `sqrt(float)` picks depends on its include set
+    (<cmath> alone: ::sqrt(double); <math.h>: the float overload) but cannot
+    change the result: narrowing sqrt((double)x) to float equals sqrtf(x) for
+    every float (double carries > 2*24+2 bits), checked below."""
+    import subprocess
+    import tempfile
+
+    src = ("#include <cmath>\n#include <type_traits>\n"
+           "float x=1.5f; static_assert(std::is_same<decltype(pow(x,2)),double>::value,\"pow\");\n"
+           "static_assert(std::is_same<decltype(std::sqrt(x)),float>::value,\"sqrt\");\nint main(){return 0;}\n")
+    with tempfile.TemporaryDirectory() as d:
+        p = os.path.join(d, "t.cpp")
+        open(p, "w").write(src)
+        subprocess.check_call(["g++", "-std=c++11", "-fsyntax-only", p])
+    rng = np.random.default_rng(11)
+    v = np.concatenate([rng.uniform(0, 4, 200000), 10.0 ** rng.uniform(-30, 30, 200000)]).astype(np.float32)
+    assert np.array_equal(np.sqrt(v), np.sqrt(v.astype(np.float64)).astype(np.float32))
+
+
+# ---------------------------------------------------------------------- NN --
+def test_nn_ties_resolve_to_lowest_index(oracle):
+    # query at origin; targets 1 and 3 are both at distance 1 (exact tie), 0 and 2 farther
+    tgt = np.array([[2, 1, 3, -1, 0], [0, 0, 0, 0, 1], [0, 0, 0, 0, 0]], np.float32)
+    src = np.zeros((3, 1), np.float32)
+    idx, dist = oracle.nn_bruteforce(src, tgt)
+    assert idx[0] == 1 and dist[0] == np.float32(1.0)
+    # first element is the seed and wins a tie with later ones (icp.cpp:572-578)
+    tgt = np.array([[1, -1, 0], [0, 0, 1], [0, 0, 0]], np.float32)
+    idx, dist = oracle.nn_bruteforce(src, tgt)
+    assert idx[0] == 0
+
+
+def test_nn_single_target_and_empty(oracle):
+    src = np.zeros((3, 4), np.float32)
+    tgt = np.ones((3, 1), np.float32)
+    idx, dist = oracle.nn_bruteforce(src, tgt)
+    assert (idx == 0).all() and np.all(dist == np.sqrt(np.float32(3.0)))
+    with pytest.raises(ValueError):
+        oracle.nn_bruteforce(src, np.zeros((3, 0), np.float32))
+
+
+@pytest.mark.parametrize("case", ["random", "lattice", "frustum"])
+def test_nn_matches_numpy_restatement(oracle, case):
+    if case == "random":
+        rng = np.random.default_rng(1)
+        src = rng.uniform(-2, 2, (3, 700)).astype(np.float32)
+        tgt = rng.uniform(-2, 2, (3, 900)).astype(np.float32)
+    elif case == "lattice":
+        p = synth.lattice_wall(30, 40)
+        src, tgt = p["source"], p["target"]
+    else:
+        p = synth.frustum_pair(1500)
+        src, tgt = p["source"], p["target"]
+    D = np_dist_matrix(src, tgt)
+    want_idx = D.argmin(axis=1).astype(np.int32)  # first minimum = lowest index
+    want_d = D[np.arange(D.shape[0]), want_idx]
+    idx, dist = oracle.nn_bruteforce(src, tgt)
+    assert np.array_equal(idx, want_idx)
+    assert np.array_equal(dist, want_d)
+    if case == "lattice":
+        ties = (D == want_d[:, None]).sum(axis=1)
+        assert (ties >= 2).sum() > 100  # the case really is tie-heavy
+    idx2, dist2 = oracle.nn_bruteforce(src, tgt, threads=4)
+    assert np.array_equal(idx, idx2) and np.array_equal(dist, dist2)
+
+
+# -------------------------------------------------------------- reductions --
+def _assoc(oracle, n=3000, seed=3):
+    p = synth.frustum_pair(n, seed=seed, rot_deg=(0, 1, 0), shift=(0.01, 0, 0))
+    src, tgt = p["source"] + 5, p["target"] + 5
+    idx, dist = oracle.nn_bruteforce(src, tgt, threads=4)
+    return src, tgt, idx, dist
+
+
+def test_offset_and_mse_sequential_float(oracle):
+    src, tgt, idx, dist = _assoc(oracle, 500)
+    maxd = float(np.median(dist))
+    off, n = oracle.calculate_offset_seq(src, tgt, idx, dist, maxd)
+    acc = np.zeros(3, np.float32)
+    cnt = 0
+    esum = np.float32(0)
+    for i in range(src.shape[1]):
+        if dist[i] < np.float32(maxd):
+            acc = acc + (src[:, i] - tgt[:, idx[i]])
+            esum = np.float32(esum + dist[i])
+            cnt += 1
+    assert 3 < cnt < src.shape[1] and n == cnt
+    assert np.array_equal(off, acc / np.float32(cnt))
+    m = np.float32(esum / np.float32(cnt))
+    assert oracle.mse_seq(dist, maxd) == np.float32(np.float64(m) * np.float64(m))
+    assert oracle.mse_seq(dist[:0], maxd) == 0
+
+
+def test_cross_moment_matches_float64_matmul(oracle):
+    src, tgt, idx, dist = _assoc(oracle)
+    M, n = oracle.cross_moment_seq(src, tgt, idx, dist, 0.75)
+    a = src.astype(np.float64).T
+    b = tgt[:, idx].astype(np.float64).T
+    want = b.T @ a  # previousMat.t() * dataMat, icp.cpp:212
+    assert n == src.shape[1]
+    assert np.allclose(M, want, rtol=1e-6, atol=0)
+
+
+def np_canonical(vals):
+    """numpy restatement of the canonical tree: vals (n, k) float64 per element."""
+    n, k = vals.shape
+    B = min(max((n + 255) // 256, 1), 256)
+    P = B * 256
+    acc = np.zeros((P, k))
+    for start in range(0, n, P):  # sequential per virtual thread
+        chunk = vals[start:start + P]
+        acc[: chunk.shape[0]] += chunk
+    acc = acc.reshape(B, 4, 64, k)
+    for m in (32, 16, 8, 4, 2, 1):
+        acc = acc + acc[:, :, np.arange(64) ^ m, :]
+    w = acc[:, :, 0, :]
+    blk = ((w[:, 0] + w[:, 1]) + w[:, 2]) + w[:, 3]
+    tot = np.zeros(k)
+    for b in range(B):
+        tot = tot + blk[b]
+    return tot
+
+
+@pytest.mark.parametrize("n", [1, 63, 257, 3000, 70000])
+def test_canonical_sums_bit_exact_vs_numpy_tree(oracle, n):
+    rng = np.random.default_rng(n)
+    src = (rng.uniform(-2, 2, (3, n)) + 5).astype(np.float32)
+    tgt = (rng.uniform(-2, 2, (3, 50)) + 5).astype(np.float32)
+    idx = rng.integers(0, 50, n).astype(np.int32)
+    dist = rng.uniform(0, 1.0, n).astype(np.float32)
+    maxd = np.float32(0.75)
+    sums, cnt = oracle.sums_canonical(src, tgt, idx, dist, maxd)
+    acc = dist < maxd
+    a = src.astype(np.float64).T
+    b = tgt[:, idx].astype(np.float64).T
+    vals = np.zeros((n, 19))
+    vals[:, 0:9] = (b[:, :, None] * a[:, None, :]).reshape(n, 9)
+    vals[:, 9:12] = (src.T - tgt[:, idx].T).astype(np.float32).astype(np.float64)
+    vals[:, 12] = dist
+    vals[:, 13:16] = a
+    vals[:, 16:19] = b
+    vals[~acc] = 0.0
+    assert cnt == acc.sum()
+    assert np.array_equal(sums, np_canonical(vals))
+    assert np.allclose(sums, vals.sum(axis=0), rtol=1e-12, atol=1e-9)
+
+
+# -------------------------------------------------------------------- solve --
+def test_svd3_against_numpy(oracle):
+    rng = np.random.default_rng(7)
+    for _ in range(50):
+        A = rng.normal(size=(3, 3)) * rng.uniform(0.1, 100)
+        U, S, V = oracle.svd3(A)
+        assert np.allclose(U @ np.diag(S) @ V.T, A, atol=1e-12 * np.abs(A).max())
+        assert np.allclose(U.T @ U, np.eye(3), atol=1e-13)
+        assert np.allclose(V.T @ V, np.eye(3), atol=1e-13)
+        assert np.allclose(S, np.linalg.svd(A, compute_uv=False), rtol=1e-12)
+        assert S[0] >= S[1] >= S[2] >= 0
+    # rank deficient input still returns orthogonal factors
+    A = np.outer([1.0, 2.0, 3.0], [0.5, -1.0, 2.0])
+    U, S, V = oracle.svd3(A)
+    assert np.allclose(U.T @ U, np.eye(3), atol=1e-12) and np.allclose(U @ np.diag(S) @ V.T, A, atol=1e-12)
+
+
+def test_solve_reference_is_polar_factor_with_column_flip(oracle):
+    rng = np.random.default_rng(8)
+    for k in range(40):
+        M = rng.normal(size=(3, 3)).astype(np.float32)
+        if k % 2:
+            M = (np.outer([5, 5, 7], [5, 5, 7]) * 100 + rng.normal(size=(3, 3))).astype(np.float32)  # icp-like
+        R = oracle.solve_reference(M)
+        U, S, Vt = np.linalg.svd(M.astype(np.float64))
+        want = Vt.T @ U.T  # icp.cpp:218
+        want = want.astype(np.float32)
+        if np.linalg.det(want.astype(np.float64)) < 0:  # icp.cpp:220-223
+            want[:, 2] *= -1
+        assert np.allclose(R, want, atol=5e-6 * max(1.0, S[0] / S[2] * 1e-3))
+
+
+def test_inv3(oracle):
+    R = oracle.make_rotation_matrix(10, 20, 30)
+    Ri = oracle.inv3(R)
+    assert np.allclose(Ri, R.T, atol=2e-7)
+    assert np.allclose(Ri.astype(np.float64) @ R.astype(np.float64), np.eye(3), atol=3e-7)
+
+
+def test_kabsch_matches_reference_python_golden(oracle):
+    """PINNED: outputs of /root/reference/rigid_transform_3D.py (see
+    tests/golden/make_kabsch_golden.py)."""
+    g = np.load(os.path.join(GOLD, "kabsch_golden.npz"))
+    names = sorted({k[:-2] for k in g.files})
+    assert len(names) == 6
+    for nme in names:
+        A, B, R, t = g[nme + "_A"], g[nme + "_B"], g[nme + "_R"], g[nme + "_t"]
+        R2, t2 = oracle.rigid_transform_3D(A, B)
+        assert np.linalg.norm(R2 - R) < 1e-9, nme  # Frobenius
+        assert np.linalg.norm(t2 - t) < 1e-9, nme
+        # the raw-sums entry point (what the GPU path feeds) agrees as well
+        n = A.shape[0]
+        R3, t3 = oracle.solve_kabsch_from_sums(n, A.sum(0), B.sum(0), A.T @ B)
+        assert np.linalg.norm(R3 - R) < 1e-8, nme
+        assert np.linalg.norm(t3 - t) < 1e-8, nme
+
+
+# ------------------------------------------------------- small host helpers --
+def test_make_rotation_matrix_known_answers(oracle):
+    assert np.array_equal(oracle.make_rotation_matrix(0, 0, 0), np.eye(3, dtype=np.float32))
+    R = oracle.make_rotation_matrix(0, 5, 0)
+    a = np.float64(np.float32(5) * np.float32(3.14159265358979) / np.float32(180))
+    c, s = np.float32(np.cos(a)), np.float32(np.sin(a))
+    assert np.array_equal(R, np.array([[c, 0, -s], [0, 1, 0], [s, 0, c]], np.float32))
+    R = oracle.make_rotation_matrix(90, 0, 0)
+    assert np.allclose(R, [[1, 0, 0], [0, 0, 1], [0, -1, 0]], atol=1e-7)
+    R = oracle.make_rotation_matrix(10, 20, 30)
+    assert np.allclose(R, synth.rot_xyz_deg(10, 20, 30), atol=2e-7)
+
+
+def test_quaternion_and_euler_known_answers(oracle):
+    q = oracle.quaternion_from_matrix(np.eye(3))
+    assert np.array_equal(q, np.array([1, 0, 0, 0], np.float32))
+    assert np.array_equal(oracle.to_euler(q), np.zeros(3, np.float32))
+    # proper rotation about z by +90 deg: [[0,-1,0],[1,0,0],[0,0,1]]
+    q = oracle.quaternion_from_matrix([[0, -1, 0], [1, 0, 0], [0, 0, 1]])
+    assert np.allclose(q, [np.sqrt(0.5), 0, 0, np.sqrt(0.5)], atol=1e-7)
+    assert np.allclose(oracle.to_euler(q), [0, 0, 90], atol=1e-4)
+    # x branch (180 deg about x): w = 0
+    q = oracle.quaternion_from_matrix(np.diag([1.0, -1.0, -1.0]))
+    assert np.allclose(np.abs(q), [0, 1, 0, 0], atol=1e-7)
+    # round trip for a generic rotation
+    R = synth.rot_xyz_deg(12, -7, 33).astype(np.float32)
+    w, x, y, z = oracle.quaternion_from_matrix(R).astype(np.float64)
+    Rq = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                   [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                   [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+    assert np.allclose(Rq, R, atol=1e-6)
+
+
+def test_transform_points(oracle):
+    rng = np.random.default_rng(9)
+    p = (rng.uniform(-3, 3, (3, 1000)) + 5).astype(np.float32)
+    R = oracle.make_rotation_matrix(3, -2, 1)
+    t = np.array([0.1, -0.2, 0.3], np.float32)
+    got = oracle.transform_points(p, R, t)
+    rp = ((R.astype(np.float64)[:, 0:1] * p[0].astype(np.float64) + R.astype(np.float64)[:, 1:2] * p[1].astype(np.float64))
+          + R.astype(np.float64)[:, 2:3] * p[2].astype(np.float64)).astype(np.float32)
+    assert np.array_equal(got, rp + t[:, None])
+
+
+def test_backproject_matches_numpy_and_formula(oracle):
+    rng = np.random.default_rng(10)
+    depth = rng.integers(0, 20000, (48, 64)).astype(np.uint16)
+    depth[rng.random(depth.shape) < 0.5] = 0
+    got = oracle.backproject(depth)
+    want = synth.backproject(depth)
+    assert got.shape == want.shape and np.array_equal(got, want)
+    # first valid pixel by hand (pointcloud.cpp:37-39: CX and FX used for y as well)
+    r, c = np.argwhere(depth != 0)[0]
+    pz = np.float32(depth[r, c]) / np.float32(5000)
+    assert got[2, 0] == pz
+    assert got[0, 0] == (np.float32(c) - synth.CX) * pz / synth.FX
+    assert got[1, 0] == (np.float32(r) - synth.CX) * pz / synth.FX
+    keep = rng.random(depth.shape) < 0.3
+    assert np.array_equal(oracle.backproject(depth, keep), synth.backproject(depth, keep))
+    f = oracle.depth_range_filter(depth)
+    assert ((f == 0) | ((f >= 1000) & (f <= 25000))).all()
+    assert np.array_equal(f != 0, (depth >= 1000) & (depth <= 25000))
+
+
+# --------------------------------------------------------------- full loop --
+def test_align_kabsch_recovers_known_motion_config1(oracle):
+    """BASELINE config 1: two 10k clouds, known 5 degree rotation."""
+    p = synth.frustum_pair(10000, seed=1)
+    r = oracle.align(p["source"], p["target"], max_iterations=40, threshold=0.0, solve=1,
+                     sum_order=1, threads=8)
+    T = r["T"].astype(np.float64)
+    # T maps source -> target: inverse of the applied motion
+    c = p["target"].astype(np.float64).mean(axis=1)
+    R_true = p["R_true"]
+    R_inv = R_true.T
+    t_inv = -R_inv @ (p["t_true"] + c - R_true @ c)
+    assert np.linalg.norm(T[:3, :3] - R_inv) < 1e-5
+    assert np.linalg.norm(T[:3, 3] - t_inv) < 1e-4
+    assert r["final_pairs"] == 10000
+    assert np.array_equal(r["idx"], np.arange(10000))
+
+
+def test_align_reference_flavour_trace_consistency(oracle):
+    """The bug-for-bug flavour: returned 3x3 is the product of per-iteration R
+    (icp.cpp:227-233), column 3 is the LAST offset only (icp.cpp:266-268)."""
+    p = synth.frustum_pair(1500, seed=4, rot_deg=(0, 2, 0), shift=(0.01, 0, 0))
+    src, tgt = p["source"] + 5, p["target"] + 5
+    r = oracle.align(src, tgt, max_iterations=6, threshold=0.0, solve=0, sum_order=0)
+    assert r["iterations"] == 6 and len(r["trace"]) == 6
+    acc = r["trace"][0]["R"].astype(np.float64)
+    for it in r["trace"][1:]:
+        acc = it["R"].astype(np.float64) @ acc
+    assert np.allclose(r["T"][:3, :3], acc, atol=1e-6)
+    assert np.array_equal(r["T"][:3, 3], r["trace"][-1]["t"])
+    assert np.array_equal(r["T"][3], [0, 0, 0, 1])
+    # sequential (reference-order) and canonical summation agree to tolerance
+    r2 = oracle.align(src, tgt, max_iterations=6, threshold=0.0, solve=0, sum_order=1)
+    assert np.linalg.norm(r2["T"].astype(np.float64) - r["T"].astype(np.float64)) < 1e-5
+
+
+def test_align_threshold_exit_and_fallback(oracle):
+    p = synth.frustum_pair(800, seed=5, rot_deg=(0, 0.5, 0), shift=(0.002, 0, 0))
+    r = oracle.align(p["source"], p["target"], max_iterations=16, threshold=1e-4, solve=1, sum_order=1)
+    assert r["iterations"] < 16 and r["final_mse"] <= np.float32(1e-4)
+    # too few pairs (2 in reach, mse above threshold) -> fallback motion (icp.cpp:163-182)
+    far = p["source"] + np.float32(100)
+    far[:, :2] = p["target"][:, :2] + np.float32(0.05)
+    lt = np.array([1, 2, 3], np.float32)
+    r = oracle.align(far, p["target"], max_iterations=16, threshold=1e-4, solve=0, last_translation=lt)
+    assert r["status"] == 1 and r["iterations"] == 0 and r["final_pairs"] == 2
+    assert np.array_equal(r["T"][:3, 3], -lt)
+    assert np.allclose(r["src_out"], far + lt[:, None])
+    # nothing in reach: errors is empty, meanSquareError returns 0 and the loop
+    # never runs (icp.cpp:155, 629) -- no fallback, identity result
+    far = p["source"] + np.float32(100)
+    r = oracle.align(far, p["target"], max_iterations=16, threshold=1e-4, solve=0)
+    assert r["final_pairs"] == 0 and r["status"] == 0 and r["iterations"] == 0
+    assert np.array_equal(r["T"], np.eye(4, dtype=np.float32))
