@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X ICP inner loop.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+          --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...)
+
+Workload (BASELINE.json configs[1]): one synthetic 640x480 Kinect frame pair,
+30% valid pixels (~92k points per cloud), 20 fixed ICP iterations.  One "step"
+= one icpk_align call = 21 brute-force NN sweeps + 20 reduce/solve/transform
+iterations, clouds already resident in HBM.  metric = ICP iterations/s (whole
+job); NN Mpoints/s and Gpairs/s are reported alongside.
+
+N > 1 is the frame-batch mode: one process per GPU, every rank
+aligns its own source frame against a key frame (target cloud) that rank 0
+broadcasts once over RCCL/xGMI; no per-iteration collective; weak scaling.
+
+The JSON line also carries
+  roofline      -- the NN kernel against the 8 TB/s HBM roofline on ALGORITHMIC
+                   bytes (Nq*Nt*12 + Nq*12 + Nq*8 per launch),
+                   duration measured with HIP events on the kernel's own stream;
+  cpu_baseline  -- the oracle's CPU restatement (OpenMP, all host cores) timed
+                   on a bounded query sample of the same workload (rank 0, N=1).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--iters", type=int, default=20, help="fixed ICP iterations per step (config 2: 20)")
+    ap.add_argument("--workload", default="kinect640x480_30pct",
+                    choices=["kinect640x480_30pct", "kinect640x480_dense", "kinect_v2_512x424", "dense1m", "frustum10k"])
+    ap.add_argument("--solve", default="reference", choices=["reference", "kabsch"])
+    ap.add_argument("--nn-mode", default="exact", choices=["exact", "filtered"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=32768, help="queries in the CPU baseline sample")
+    return ap.parse_args()
+
+
+def make_workload(name, seed):
+    from icp_slam_prototype_amd import synth
+
+    if name == "kinect640x480_30pct":
+        return synth.kinect_pair(480, 640, valid=0.30, seed=seed)
+    if name == "kinect640x480_dense":
+        return synth.kinect_pair(480, 640, valid=1.0, seed=seed)
+    if name == "kinect_v2_512x424":
+        return synth.kinect_pair(424, 512, valid=1.0, seed=seed, fx=synth.K2_FX, cx=synth.K2_CX)
+    if name == "dense1m":
+        return synth.dense_pair(1_000_000, seed=seed)
+    return synth.frustum_pair(10000, seed=seed)
+
+
+def cpu_baseline(src, tgt, sample, solve):
+    """Oracle (CPU restatement, kind 'port') on the host cores: NN sweep over a
+    contiguous query sample against the full target, scaled linearly to Nq, plus
+    the reduce/solve/transform of one iteration measured on the full clouds."""
+    from oracle import icp_oracle as o
+
+    threads = o.max_threads()
+    nq = src.shape[1]
+    m = min(sample, nq)
+    sub = np.ascontiguousarray(src[:, :m])
+    o.nn_bruteforce(sub[:, :256], tgt, threads=threads)  # warm
+    t0 = time.perf_counter()
+    idx, dist = o.nn_bruteforce(sub, tgt, threads=threads)
+    t_nn = (time.perf_counter() - t0) * nq / m
+    idx_full = np.resize(idx, nq)
+    dist_full = np.resize(dist, nq)
+    t0 = time.perf_counter()
+    sums, cnt = o.sums_canonical(src, tgt, idx_full, dist_full, 0.75)
+    M = sums[:9].astype(np.float32)
+    R = o.solve_reference(M)
+    o.transform_points(src, o.inv3(R), -(sums[9:12] / max(cnt, 1)).astype(np.float32))
+    t_rest = time.perf_counter() - t0
+    it_s = 1.0 / (t_nn + t_rest)
+    return {
+        "value": it_s, "unit": "iter/s", "cores": threads, "kind": "port",
+        "sample": f"NN sweep of {m} of {nq} queries x {tgt.shape[1]} targets on {threads} OpenMP threads "
+                  f"(scaled linearly to Nq) + full reduce/solve/transform; oracle/icp_oracle.c, gcc -O2",
+        "nn_s_per_sweep": t_nn, "gpairs_per_s": nq * tgt.shape[1] / t_nn / 1e9,
+    }
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import torch
+
+    from icp_slam_prototype_amd import binding
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    # ---- workload: own source frame per rank; key frame (target) from rank 0 ----
+    base_seed = 2
+    w = make_workload(args.workload, base_seed + 100 * rank if world > 1 else base_seed)
+    src_h = np.ascontiguousarray(w["source"])
+    src_d = torch.from_numpy(src_h).to(dev)
+    if world > 1:
+        n_t = torch.tensor([w["target"].shape[1]], dtype=torch.int64, device=dev)
+        dist.broadcast(n_t, src=0)
+        nt = int(n_t.item())
+        tgt_d = torch.from_numpy(np.ascontiguousarray(w["target"])).to(dev) if rank == 0 else \
+            torch.empty((3, nt), dtype=torch.float32, device=dev)
+        dist.broadcast(tgt_d, src=0)  # RCCL broadcast of the target SoA over xGMI
+        tgt_h = tgt_d.cpu().numpy()
+    else:
+        tgt_h = np.ascontiguousarray(w["target"])
+        tgt_d = torch.from_numpy(tgt_h).to(dev)
+    torch.cuda.synchronize()
+    nq, nt = src_d.shape[1], tgt_d.shape[1]
+
+    ctx = binding.Context(local_rank)
+    es = src_d.element_size()
+    ctx.set_target_device(tgt_d.data_ptr(), tgt_d.data_ptr() + nt * es, tgt_d.data_ptr() + 2 * nt * es, nt)
+    ctx.set_source_device(src_d.data_ptr(), src_d.data_ptr() + nq * es, src_d.data_ptr() + 2 * nq * es, nq)
+
+    params = binding.default_params(
+        max_iterations=args.iters, fixed_iterations=1, profile=1,
+        solve=binding.SOLVE_REFERENCE if args.solve == "reference" else binding.SOLVE_KABSCH,
+        nn_mode=binding.NN_EXACT if args.nn_mode == "exact" else binding.NN_FILTERED)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        ctx.align(params)
+    sync_all()
+    t0 = time.perf_counter()
+    nn_ms = 0.0
+    nn_launches = 0
+    red_ms = tr_ms = 0.0
+    iters_done = 0
+    for _ in range(args.steps):
+        T, st, rc = ctx.align(params)
+        nn_ms += st.nn_ms_total
+        red_ms += st.reduce_ms_total
+        tr_ms += st.transform_ms_total
+        nn_launches += st.nn_launches
+        iters_done += st.iterations
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        agg = torch.tensor([iters_done, nn_launches * nq, nn_launches * nq * nt], dtype=torch.float64, device=dev)
+        dist.all_reduce(agg, op=dist.ReduceOp.SUM)
+        total_iters, total_queries, total_pairs = (float(v) for v in agg.tolist())
+    else:
+        total_iters, total_queries, total_pairs = float(iters_done), float(nn_launches * nq), float(nn_launches) * nq * nt
+
+    if rank == 0:
+        avg_nn_s = nn_ms / max(nn_launches, 1) / 1e3
+        alg_bytes = float(nq) * nt * 12 + nq * 12 + nq * 8
+        achieved = alg_bytes / avg_nn_s / 1e9
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tfile):
+            traffic = json.load(open(tfile)).get(f"{args.workload}:{args.nn_mode}")
+        out = {
+            "metric": "ICP iterations/sec + NN Mpoints/sec at 307k-pt Kinect cloud, 1/2/4/8 GPU",
+            "value": total_iters / elapsed,
+            "unit": "iter/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32 coordinates, f64 pair arithmetic (reference float semantics)",
+            "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {nq} source x {nt} target points, {args.iters} fixed ICP "
+                                   f"iterations per step, solve={args.solve}, nn={args.nn_mode}",
+                       "frame_pairs_per_step": world, "parallelism": f"frame-batch x{world}" if world > 1 else "1 GPU"},
+            "nn_mpoints_per_s": total_queries / elapsed / 1e6,
+            "nn_gpairs_per_s_wall": total_pairs / elapsed / 1e9,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "nn_exact_kernel" if args.nn_mode == "exact" else "nn_filtered_kernel",
+                         "avg_launch_ms": avg_nn_s * 1e3, "algorithmic_bytes_per_launch": alg_bytes,
+                         "gpairs_per_s_kernel": nq * nt / avg_nn_s / 1e9,
+                         "note": "algorithmic operand bytes (LDS tiling re-uses each target tile across 256 "
+                                 "queries, so compulsory HBM traffic is ~3 MB/launch; the kernel is VALU-bound)"},
+            "stage_ms_per_step": {"nn": nn_ms / args.steps, "reduce": red_ms / args.steps,
+                                  "transform": tr_ms / args.steps},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(src_h, tgt_h, args.cpu_sample, args.solve)
+            out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    ctx.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,342 @@
+"""ctypes binding of include/icpk.h (lib/libicpk.so).  No torch types cross the
+boundary: device buffers are passed as integer addresses.
+
+There is no CPU fallback: if the library is missing `load()` raises, and
+`Context()` raises when no HIP device is usable (ICPK_E_NO_DEVICE).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libicpk.so")
+
+OK = 0
+W_TOO_FEW_PAIRS = 1
+E_ARG, E_EMPTY_TARGET, E_HIP, E_NOT_SET, E_NO_DEVICE = -1, -2, -3, -4, -5
+SOLVE_REFERENCE, SOLVE_KABSCH = 0, 1
+NN_EXACT, NN_FILTERED = 0, 1
+NSUM = 19
+
+# every symbol include/icpk.h declares (tests/test_abi.py checks the header against this list)
+SYMBOLS = [
+    "icpk_version", "icpk_create", "icpk_destroy", "icpk_last_error", "icpk_default_params",
+    "icpk_set_log_callback", "icpk_stream", "icpk_set_target", "icpk_set_source", "icpk_set_target_device",
+    "icpk_set_source_device", "icpk_reset_source", "icpk_get_source", "icpk_source_size", "icpk_target_size",
+    "icpk_nn", "icpk_reduce", "icpk_transform_source", "icpk_get_associations", "icpk_align",
+    "icpk_align_batch", "icpk_backproject", "icpk_pair_distance", "icpk_make_rotation_matrix",
+    "icpk_matrix_to_quaternion", "icpk_quaternion_to_euler", "icpk_solve_reference", "icpk_solve_kabsch",
+]
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("max_iterations", C.c_int32),
+        ("threshold", C.c_float),
+        ("max_nn_dist", C.c_float),
+        ("min_pairs", C.c_int32),
+        ("solve", C.c_int32),
+        ("fixed_iterations", C.c_int32),
+        ("nn_mode", C.c_int32),
+        ("profile", C.c_int32),
+        ("last_rotation", C.c_float * 9),
+        ("last_translation", C.c_float * 3),
+    ]
+
+
+class Stats(C.Structure):
+    _fields_ = [
+        ("iterations", C.c_int32),
+        ("status", C.c_int32),
+        ("final_pairs", C.c_int32),
+        ("final_mse", C.c_float),
+        ("nn_launches", C.c_int32),
+        ("reserved", C.c_int32),
+        ("nn_ms_total", C.c_float),
+        ("reduce_ms_total", C.c_float),
+        ("transform_ms_total", C.c_float),
+        ("total_ms", C.c_float),
+    ]
+
+
+class Pair(C.Structure):
+    _fields_ = [
+        ("sx", C.POINTER(C.c_float)), ("sy", C.POINTER(C.c_float)), ("sz", C.POINTER(C.c_float)),
+        ("ns", C.c_int32),
+        ("tx", C.POINTER(C.c_float)), ("ty", C.POINTER(C.c_float)), ("tz", C.POINTER(C.c_float)),
+        ("nt", C.c_int32),
+    ]
+
+
+LOG_FN = C.CFUNCTYPE(None, C.c_int, C.c_int, C.c_double, C.c_void_p)
+
+_lib = None
+
+
+class IcpkError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"icpk status {code}: {msg}")
+        self.code = code
+
+
+def load():
+    """Load libicpk.so.  Raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    lib = C.CDLL(LIB_PATH)
+    lib.icpk_version.restype = C.c_char_p
+    lib.icpk_last_error.restype = C.c_char_p
+    lib.icpk_last_error.argtypes = [C.c_void_p]
+    lib.icpk_stream.restype = C.c_void_p
+    lib.icpk_stream.argtypes = [C.c_void_p]
+    lib.icpk_create.argtypes = [C.POINTER(C.c_void_p), C.c_int]
+    lib.icpk_destroy.argtypes = [C.c_void_p]
+    lib.icpk_destroy.restype = None
+    fp = C.POINTER(C.c_float)
+    for name in ("icpk_set_target", "icpk_set_source"):
+        getattr(lib, name).argtypes = [C.c_void_p, fp, fp, fp, C.c_int32]
+    for name in ("icpk_set_target_device", "icpk_set_source_device"):
+        getattr(lib, name).argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
+    lib.icpk_reset_source.argtypes = [C.c_void_p]
+    lib.icpk_get_source.argtypes = [C.c_void_p, fp, fp, fp]
+    lib.icpk_source_size.argtypes = [C.c_void_p]
+    lib.icpk_target_size.argtypes = [C.c_void_p]
+    lib.icpk_nn.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), fp]
+    lib.icpk_reduce.argtypes = [C.c_void_p, C.c_float, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    lib.icpk_transform_source.argtypes = [C.c_void_p, fp, fp]
+    lib.icpk_get_associations.argtypes = [C.c_void_p, C.POINTER(C.c_int32), fp]
+    lib.icpk_align.argtypes = [C.c_void_p, C.POINTER(Params), fp, C.POINTER(Stats)]
+    lib.icpk_align_batch.argtypes = [C.c_void_p, C.c_int32, C.POINTER(Pair), C.POINTER(Params), fp, C.POINTER(Stats)]
+    lib.icpk_backproject.argtypes = [C.c_void_p, C.POINTER(C.c_uint16), C.c_int32, C.c_int32, C.c_float, C.c_float,
+                                     fp, C.c_int32]
+    lib.icpk_pair_distance.argtypes = [C.c_void_p, fp, fp, fp, C.c_int32]
+    lib.icpk_default_params.argtypes = [C.POINTER(Params)]
+    lib.icpk_default_params.restype = None
+    lib.icpk_set_log_callback.argtypes = [C.c_void_p, LOG_FN, C.c_void_p]
+    lib.icpk_make_rotation_matrix.argtypes = [C.c_float, C.c_float, C.c_float, fp]
+    lib.icpk_make_rotation_matrix.restype = None
+    lib.icpk_matrix_to_quaternion.argtypes = [fp, fp]
+    lib.icpk_matrix_to_quaternion.restype = None
+    lib.icpk_quaternion_to_euler.argtypes = [fp, fp]
+    lib.icpk_quaternion_to_euler.restype = None
+    lib.icpk_solve_reference.argtypes = [fp, fp]
+    lib.icpk_solve_reference.restype = None
+    dp = C.POINTER(C.c_double)
+    lib.icpk_solve_kabsch.argtypes = [C.c_int64, dp, dp, dp, dp, dp]
+    lib.icpk_solve_kabsch.restype = None
+    _lib = lib
+    return lib
+
+
+def _f(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def default_params(**kw):
+    p = Params()
+    load().icpk_default_params(C.byref(p))
+    for k, v in kw.items():
+        if k in ("last_rotation", "last_translation"):
+            arr = _f(v).reshape(-1)
+            getattr(p, k)[:] = [float(x) for x in arr]
+        else:
+            setattr(p, k, v)
+    return p
+
+
+# ---- host helpers (no device) ------------------------------------------------
+def make_rotation_matrix(x, y, z):
+    out = np.zeros(9, np.float32)
+    load().icpk_make_rotation_matrix(x, y, z, _fp(out))
+    return out.reshape(3, 3)
+
+
+def matrix_to_quaternion(m):
+    m = _f(m).reshape(9)
+    q = np.zeros(4, np.float32)
+    load().icpk_matrix_to_quaternion(_fp(m), _fp(q))
+    return q
+
+
+def quaternion_to_euler(q):
+    q = _f(q).reshape(4)
+    e = np.zeros(3, np.float32)
+    load().icpk_quaternion_to_euler(_fp(q), _fp(e))
+    return e
+
+
+def solve_reference(M):
+    M = _f(M).reshape(9)
+    R = np.zeros(9, np.float32)
+    load().icpk_solve_reference(_fp(M), _fp(R))
+    return R.reshape(3, 3)
+
+
+def solve_kabsch(n, sa, sb, sab):
+    dp = C.POINTER(C.c_double)
+    sa = np.ascontiguousarray(sa, np.float64)
+    sb = np.ascontiguousarray(sb, np.float64)
+    sab = np.ascontiguousarray(sab, np.float64).reshape(9)
+    R = np.zeros(9)
+    t = np.zeros(3)
+    load().icpk_solve_kabsch(int(n), sa.ctypes.data_as(dp), sb.ctypes.data_as(dp), sab.ctypes.data_as(dp),
+                             R.ctypes.data_as(dp), t.ctypes.data_as(dp))
+    return R.reshape(3, 3), t
+
+
+class Context:
+    """One GPU + one HIP stream (icpk_ctx)."""
+
+    def __init__(self, device=0):
+        self._lib = load()
+        h = C.c_void_p()
+        rc = self._lib.icpk_create(C.byref(h), int(device))
+        if rc != OK:
+            raise IcpkError(rc, "icpk_create failed (no usable HIP device: there is no CPU fallback)")
+        self._h = h
+        self._log_ref = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.icpk_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _chk(self, rc):
+        if rc < 0:
+            raise IcpkError(rc, self._lib.icpk_last_error(self._h).decode())
+        return rc
+
+    @property
+    def stream(self):
+        return self._lib.icpk_stream(self._h)
+
+    # -- clouds ---------------------------------------------------------------
+    def set_target(self, pts):
+        x, y, z = (_f(pts[k]) for k in range(3))
+        self._chk(self._lib.icpk_set_target(self._h, _fp(x), _fp(y), _fp(z), x.size))
+
+    def set_source(self, pts):
+        x, y, z = (_f(pts[k]) for k in range(3))
+        self._chk(self._lib.icpk_set_source(self._h, _fp(x), _fp(y), _fp(z), x.size))
+
+    def set_target_device(self, px, py, pz, n):
+        self._chk(self._lib.icpk_set_target_device(self._h, px, py, pz, n))
+
+    def set_source_device(self, px, py, pz, n):
+        self._chk(self._lib.icpk_set_source_device(self._h, px, py, pz, n))
+
+    def reset_source(self):
+        self._chk(self._lib.icpk_reset_source(self._h))
+
+    def get_source(self):
+        n = self._lib.icpk_source_size(self._h)
+        out = np.empty((3, n), np.float32)
+        self._chk(self._lib.icpk_get_source(self._h, _fp(out[0]), _fp(out[1]), _fp(out[2])))
+        return out
+
+    @property
+    def source_size(self):
+        return self._lib.icpk_source_size(self._h)
+
+    @property
+    def target_size(self):
+        return self._lib.icpk_target_size(self._h)
+
+    # -- steps ------------------------------------------------------------------
+    def nn(self, nn_mode=NN_EXACT, fetch=True):
+        n = self.source_size
+        if not fetch:
+            self._chk(self._lib.icpk_nn(self._h, nn_mode, None, None))
+            return None
+        idx = np.empty(n, np.int32)
+        dist = np.empty(n, np.float32)
+        self._chk(self._lib.icpk_nn(self._h, nn_mode, idx.ctypes.data_as(C.POINTER(C.c_int32)), _fp(dist)))
+        return idx, dist
+
+    def get_associations(self):
+        n = self.source_size
+        idx = np.empty(n, np.int32)
+        dist = np.empty(n, np.float32)
+        self._chk(self._lib.icpk_get_associations(self._h, idx.ctypes.data_as(C.POINTER(C.c_int32)), _fp(dist)))
+        return idx, dist
+
+    def reduce(self, max_dist=0.75):
+        sums = np.zeros(NSUM, np.float64)
+        cnt = C.c_int64(0)
+        self._chk(self._lib.icpk_reduce(self._h, max_dist, sums.ctypes.data_as(C.POINTER(C.c_double)), C.byref(cnt)))
+        return sums, cnt.value
+
+    def transform_source(self, R, t):
+        R = _f(R).reshape(9)
+        t = _f(t).reshape(3)
+        self._chk(self._lib.icpk_transform_source(self._h, _fp(R), _fp(t)))
+
+    def pair_distance(self, a, b):
+        a = _f(a)
+        b = _f(b)
+        n = a.shape[1]
+        out = np.empty(n, np.float32)
+        self._chk(self._lib.icpk_pair_distance(self._h, _fp(a), _fp(b), _fp(out), n))
+        return out
+
+    def backproject(self, depth, which=0, fx=468.60, cx=318.27, offset=None):
+        depth = np.ascontiguousarray(depth, np.uint16)
+        rows, cols = depth.shape
+        off = None if offset is None else _f(offset)
+        n = self._chk(self._lib.icpk_backproject(self._h, depth.ctypes.data_as(C.POINTER(C.c_uint16)), rows, cols,
+                                                 fx, cx, None if off is None else _fp(off), which))
+        return n
+
+    # -- loop ---------------------------------------------------------------------
+    def align(self, params=None, **kw):
+        p = params if params is not None else default_params(**kw)
+        T = np.zeros(16, np.float32)
+        st = Stats()
+        rc = self._chk(self._lib.icpk_align(self._h, C.byref(p), _fp(T), C.byref(st)))
+        return T.reshape(4, 4), st, rc
+
+    def align_batch(self, pairs, params=None, **kw):
+        """pairs: list of (source (3,Ns), target (3,Nt)) host arrays."""
+        p = params if params is not None else default_params(**kw)
+        n = len(pairs)
+        arr = (Pair * max(n, 1))()
+        keep = []
+        for b, (s, t) in enumerate(pairs):
+            sx, sy, sz = (_f(s[k]) for k in range(3))
+            tx, ty, tz = (_f(t[k]) for k in range(3))
+            keep.append((sx, sy, sz, tx, ty, tz))
+            arr[b].sx, arr[b].sy, arr[b].sz, arr[b].ns = _fp(sx), _fp(sy), _fp(sz), sx.size
+            arr[b].tx, arr[b].ty, arr[b].tz, arr[b].nt = _fp(tx), _fp(ty), _fp(tz), tx.size
+        T = np.zeros((max(n, 1), 16), np.float32)
+        st = (Stats * max(n, 1))()
+        rc = self._lib.icpk_align_batch(self._h, n, arr, C.byref(p), _fp(T), st)
+        return T[:n].reshape(n, 4, 4), list(st)[:n], rc
+
+    def set_log_callback(self, fn):
+        """fn(key, quantity, usec) -- same shape as logDeltaTime (SLAM.hpp:30)."""
+        if fn is None:
+            self._log_ref = LOG_FN()
+        else:
+            self._log_ref = LOG_FN(lambda k, q, us, _u: fn(k, q, us))
+        self._chk(self._lib.icpk_set_log_callback(self._h, self._log_ref, None))

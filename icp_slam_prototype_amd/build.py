@@ -1,0 +1,49 @@
+"""Build recipe for lib/libicpk.so (hipcc, gfx950 only) -- run by
+__graft_entry__.build().  hipcc cross-compiles without a GPU."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libicpk.so")
+
+SOURCES = ["icpk_api.cpp", "solve.cpp", "kernels_nn.hip", "kernels_reduce.hip", "kernels_transform.hip",
+           "kernels_backproject.hip"]
+
+# -ffp-contract=off: the exact kernels spell out every fma they want; nothing may
+# be fused behind their back (host solve included).  No -ffast-math anywhere.
+FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+         "-Wall", "-Wno-unused-result", "-I", os.path.join(ROOT, "include"), "-I", CSRC]
+
+
+def _newest_src():
+    paths = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")]
+    paths.append(os.path.join(ROOT, "include", "icpk.h"))
+    return max(os.path.getmtime(p) for p in paths)
+
+
+def build(force=False, verbose=False, extra=()):
+    os.makedirs(LIBDIR, exist_ok=True)
+    if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= _newest_src():
+        return LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objs = []
+    for s in SOURCES:
+        o = os.path.join(LIBDIR, s.rsplit(".", 1)[0] + ".o")
+        cmd = [hipcc] + FLAGS + list(extra) + ["-x", "hip", "-c", os.path.join(CSRC, s), "-o", o]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+        objs.append(o)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,691 @@
+// icpk_api.cpp -- host side of libicpk.so: context, device buffers, the ICP loop
+// (icp.cpp:98-268 in its frame-pair formulation) and the C ABI of include/icpk.h.
+//
+// One context = one GPU + one HIP stream.  Per iteration the host sees exactly
+// one small device->host copy (19 sums + count, 160 bytes, pinned) and sends the
+// next 3x4 transform as kernel arguments.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "icpk.h"
+#include "icpk_internal.h"
+#include "solve.h"
+
+using namespace icpk;
+
+namespace {
+
+struct Cloud {
+  float* base = nullptr;
+  int n = 0;
+  int cap = 0;  // floats per plane, multiple of NN_TILE
+  float* x() const { return base; }
+  float* y() const { return base + cap; }
+  float* z() const { return base + 2 * (size_t)cap; }
+};
+
+inline int round_up(int v, int m) { return ((v + m - 1) / m) * m; }
+
+}  // namespace
+
+struct icpk_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  Cloud tgt, src0, src;
+  bool have_tgt = false, have_src = false, have_assoc = false;
+  nn_key_t* best = nullptr;
+  nn_key_t* seed = nullptr;
+  int32_t* idx = nullptr;
+  float* dist = nullptr;
+  int assoc_cap = 0;
+  double* partial = nullptr;
+  int* pcount = nullptr;
+  double* red_out = nullptr;   // device, 20 x 8 bytes
+  double* red_host = nullptr;  // pinned, 20 x 8 bytes
+  uint16_t* depth_dev = nullptr;
+  int depth_cap = 0;
+  int* bp_counts = nullptr;
+  int bp_counts_cap = 0;
+  int* bp_n_host = nullptr;  // pinned
+  std::vector<hipEvent_t> events;
+  int target_blocks = 16384;
+  std::string err;
+  icpk_log_fn log_fn = nullptr;
+  void* log_user = nullptr;
+  std::chrono::steady_clock::time_point log_last;
+};
+
+namespace {
+
+#define ICPK_HIP(ctx, call)                                                                      \
+  do {                                                                                           \
+    hipError_t e__ = (call);                                                                     \
+    if (e__ != hipSuccess) {                                                                     \
+      (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e__);                           \
+      return ICPK_E_HIP;                                                                         \
+    }                                                                                            \
+  } while (0)
+
+int fail(icpk_ctx* ctx, int code, const char* msg) {
+  if (ctx) ctx->err = msg;
+  return code;
+}
+
+int ensure_cloud(icpk_ctx* ctx, Cloud& c, int n) {
+  const int cap = round_up(n < 1 ? 1 : n, NN_TILE);
+  if (cap > c.cap) {
+    if (c.base) ICPK_HIP(ctx, hipFree(c.base));
+    c.base = nullptr;
+    c.cap = 0;
+    ICPK_HIP(ctx, hipMalloc((void**)&c.base, (size_t)3 * cap * sizeof(float)));
+    c.cap = cap;
+  }
+  c.n = n;
+  return ICPK_OK;
+}
+
+int ensure_assoc(icpk_ctx* ctx, int nq) {
+  const int cap = round_up(nq < 1 ? 1 : nq, NN_TILE);
+  if (cap > ctx->assoc_cap) {
+    if (ctx->best) ICPK_HIP(ctx, hipFree(ctx->best));
+    if (ctx->seed) ICPK_HIP(ctx, hipFree(ctx->seed));
+    if (ctx->idx) ICPK_HIP(ctx, hipFree(ctx->idx));
+    if (ctx->dist) ICPK_HIP(ctx, hipFree(ctx->dist));
+    ctx->best = ctx->seed = nullptr;
+    ctx->idx = nullptr;
+    ctx->dist = nullptr;
+    ctx->assoc_cap = 0;
+    ICPK_HIP(ctx, hipMalloc((void**)&ctx->best, (size_t)cap * sizeof(nn_key_t)));
+    ICPK_HIP(ctx, hipMalloc((void**)&ctx->seed, (size_t)cap * sizeof(nn_key_t)));
+    ICPK_HIP(ctx, hipMalloc((void**)&ctx->idx, (size_t)cap * sizeof(int32_t)));
+    ICPK_HIP(ctx, hipMalloc((void**)&ctx->dist, (size_t)cap * sizeof(float)));
+    ctx->assoc_cap = cap;
+  }
+  return ICPK_OK;
+}
+
+// pad value: +inf for targets (a padded target is never nearer than a real
+// one), 0 for sources (padded queries are computed and discarded)
+int upload_cloud(icpk_ctx* ctx, Cloud& c, const float* x, const float* y, const float* z, int n, float pad,
+                 hipMemcpyKind kind) {
+  if (n < 0 || (n > 0 && (!x || !y || !z))) return fail(ctx, ICPK_E_ARG, "bad cloud pointers/size");
+  int rc = ensure_cloud(ctx, c, n);
+  if (rc) return rc;
+  if (n > 0) {
+    ICPK_HIP(ctx, hipMemcpyAsync(c.x(), x, (size_t)n * sizeof(float), kind, ctx->stream));
+    ICPK_HIP(ctx, hipMemcpyAsync(c.y(), y, (size_t)n * sizeof(float), kind, ctx->stream));
+    ICPK_HIP(ctx, hipMemcpyAsync(c.z(), z, (size_t)n * sizeof(float), kind, ctx->stream));
+  }
+  launch_fill_f32(c.x() + n, c.cap - n, pad, ctx->stream);
+  launch_fill_f32(c.y() + n, c.cap - n, pad, ctx->stream);
+  launch_fill_f32(c.z() + n, c.cap - n, pad, ctx->stream);
+  ICPK_HIP(ctx, hipGetLastError());
+  // host buffers are only valid for the duration of the call
+  ICPK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return ICPK_OK;
+}
+
+int copy_src0_to_src(icpk_ctx* ctx) {
+  int rc = ensure_cloud(ctx, ctx->src, ctx->src0.n);
+  if (rc) return rc;
+  const Cloud &a = ctx->src0, &b = ctx->src;
+  if (a.cap == b.cap) {
+    ICPK_HIP(ctx, hipMemcpyAsync(b.base, a.base, (size_t)3 * a.cap * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+  } else {  // capacities can differ after a shrink: copy plane by plane, padded part included
+    const int m = round_up(a.n < 1 ? 1 : a.n, NN_TILE);
+    ICPK_HIP(ctx, hipMemcpyAsync(b.x(), a.x(), (size_t)m * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+    ICPK_HIP(ctx, hipMemcpyAsync(b.y(), a.y(), (size_t)m * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+    ICPK_HIP(ctx, hipMemcpyAsync(b.z(), a.z(), (size_t)m * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+  }
+  return ICPK_OK;
+}
+
+hipEvent_t get_event(icpk_ctx* ctx, size_t k) {
+  while (ctx->events.size() <= k) {
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    ctx->events.push_back(e);
+  }
+  return ctx->events[k];
+}
+
+void log_delta(icpk_ctx* ctx, int key, int quantity) {
+  if (!ctx->log_fn) return;
+  const auto now = std::chrono::steady_clock::now();
+  const double us = std::chrono::duration<double, std::micro>(now - ctx->log_last).count();
+  ctx->log_last = now;
+  ctx->log_fn(key, quantity, us, ctx->log_user);
+}
+
+int check_ready(icpk_ctx* ctx) {
+  if (!ctx) return ICPK_E_ARG;
+  if (!ctx->have_tgt || !ctx->have_src) return fail(ctx, ICPK_E_NOT_SET, "source or target cloud not set");
+  if (ctx->tgt.n <= 0) return fail(ctx, ICPK_E_EMPTY_TARGET, "target cloud is empty");
+  return ICPK_OK;
+}
+
+// enqueue one NN sweep (K1) over the working source
+int enqueue_nn(icpk_ctx* ctx, int nn_mode) {
+  if (nn_mode != ICPK_NN_EXACT) return fail(ctx, ICPK_E_ARG, "unknown nn_mode");
+  const int nq = ctx->src.n;
+  int rc = ensure_assoc(ctx, nq);
+  if (rc) return rc;
+  if (nq == 0) {
+    ctx->have_assoc = true;
+    return ICPK_OK;
+  }
+  NnArgs a;
+  a.qx = ctx->src.x();
+  a.qy = ctx->src.y();
+  a.qz = ctx->src.z();
+  a.nq = nq;
+  a.tx = ctx->tgt.x();
+  a.ty = ctx->tgt.y();
+  a.tz = ctx->tgt.z();
+  a.nt_pad = round_up(ctx->tgt.n, NN_TILE);
+  const int ntiles = a.nt_pad / NN_TILE;
+  const int nqb = (nq + NN_THREADS - 1) / NN_THREADS;
+  int nchunks = (ctx->target_blocks + nqb - 1) / nqb;
+  if (nchunks < 1) nchunks = 1;
+  if (nchunks > ntiles) nchunks = ntiles;
+  a.tiles_per_chunk = (ntiles + nchunks - 1) / nchunks;
+  a.best = ctx->best;
+  launch_fill_u64(ctx->best, nq, NN_KEY_INIT, ctx->stream);
+  launch_nn_exact(a, ctx->stream);
+  ICPK_HIP(ctx, hipGetLastError());
+  ctx->have_assoc = true;
+  return ICPK_OK;
+}
+
+// enqueue K2 and the 160-byte read-back; caller synchronises
+int enqueue_reduce(icpk_ctx* ctx, float max_dist) {
+  const int nq = ctx->src.n;
+  launch_assoc_reduce(ctx->best, ctx->src.x(), ctx->src.y(), ctx->src.z(), nq, ctx->tgt.x(), ctx->tgt.y(), ctx->tgt.z(),
+                      max_dist, ctx->idx, ctx->dist, ctx->partial, ctx->pcount, ctx->red_out, ctx->stream);
+  ICPK_HIP(ctx, hipGetLastError());
+  ICPK_HIP(ctx, hipMemcpyAsync(ctx->red_host, ctx->red_out, (NSUM + 1) * sizeof(double), hipMemcpyDeviceToHost,
+                               ctx->stream));
+  return ICPK_OK;
+}
+
+float mse_from(const double* sums, int64_t n) {
+  // icp.cpp:622-638: (mean distance)^2, evaluated from the double sum
+  if (n <= 0) return 0.f;
+  const float m = (float)(sums[12] / (double)n);
+  return (float)((double)m * (double)m);
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* icpk_version(void) { return ICPK_VERSION_STRING; }
+
+void icpk_default_params(icpk_params* p) {
+  if (!p) return;
+  std::memset(p, 0, sizeof(*p));
+  p->max_iterations = ICPK_DEFAULT_MAX_ITERATIONS;
+  p->threshold = ICPK_DEFAULT_THRESHOLD;
+  p->max_nn_dist = ICPK_MAX_NN_DISTANCE;
+  p->min_pairs = ICPK_MIN_PAIRS;
+  p->solve = ICPK_SOLVE_REFERENCE;
+  p->nn_mode = ICPK_NN_EXACT;
+  p->last_rotation[0] = p->last_rotation[4] = p->last_rotation[8] = 1.f;
+}
+
+int icpk_create(icpk_ctx** out, int device_id) {
+  if (!out) return ICPK_E_ARG;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return ICPK_E_NO_DEVICE;
+  if (device_id < 0 || device_id >= ndev) return ICPK_E_NO_DEVICE;
+  if (hipSetDevice(device_id) != hipSuccess) return ICPK_E_NO_DEVICE;
+  icpk_ctx* ctx = new icpk_ctx();
+  ctx->device = device_id;
+  bool ok = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess;
+  ok = ok && hipMalloc((void**)&ctx->partial, (size_t)RED_MAX_BLOCKS * NSUM * sizeof(double)) == hipSuccess;
+  ok = ok && hipMalloc((void**)&ctx->pcount, (size_t)RED_MAX_BLOCKS * sizeof(int)) == hipSuccess;
+  ok = ok && hipMalloc((void**)&ctx->red_out, (NSUM + 1) * sizeof(double)) == hipSuccess;
+  ok = ok && hipHostMalloc((void**)&ctx->red_host, (NSUM + 1) * sizeof(double), hipHostMallocDefault) == hipSuccess;
+  ok = ok && hipHostMalloc((void**)&ctx->bp_n_host, sizeof(int), hipHostMallocDefault) == hipSuccess;
+  if (!ok) {
+    icpk_destroy(ctx);
+    return ICPK_E_HIP;
+  }
+  if (const char* e = std::getenv("ICPK_NN_TARGET_BLOCKS")) {
+    const int v = std::atoi(e);
+    if (v > 0) ctx->target_blocks = v;
+  }
+  ctx->log_last = std::chrono::steady_clock::now();
+  *out = ctx;
+  return ICPK_OK;
+}
+
+void icpk_destroy(icpk_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  for (hipEvent_t e : ctx->events) (void)hipEventDestroy(e);
+  void* dev[] = {ctx->tgt.base, ctx->src0.base, ctx->src.base, ctx->best,      ctx->seed,     ctx->idx,
+                 ctx->dist,     ctx->partial,   ctx->pcount,   ctx->red_out,   ctx->depth_dev, ctx->bp_counts};
+  for (void* p : dev)
+    if (p) (void)hipFree(p);
+  if (ctx->red_host) (void)hipHostFree(ctx->red_host);
+  if (ctx->bp_n_host) (void)hipHostFree(ctx->bp_n_host);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+const char* icpk_last_error(const icpk_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int icpk_set_log_callback(icpk_ctx* ctx, icpk_log_fn fn, void* user) {
+  if (!ctx) return ICPK_E_ARG;
+  ctx->log_fn = fn;
+  ctx->log_user = user;
+  ctx->log_last = std::chrono::steady_clock::now();
+  return ICPK_OK;
+}
+
+void* icpk_stream(icpk_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+static int set_target_impl(icpk_ctx* ctx, const float* x, const float* y, const float* z, int32_t n, hipMemcpyKind k) {
+  if (!ctx) return ICPK_E_ARG;
+  ICPK_HIP(ctx, hipSetDevice(ctx->device));
+  int rc = upload_cloud(ctx, ctx->tgt, x, y, z, n, __builtin_inff(), k);
+  if (rc) return rc;
+  ctx->have_tgt = true;
+  ctx->have_assoc = false;
+  return ICPK_OK;
+}
+
+static int set_source_impl(icpk_ctx* ctx, const float* x, const float* y, const float* z, int32_t n, hipMemcpyKind k) {
+  if (!ctx) return ICPK_E_ARG;
+  ICPK_HIP(ctx, hipSetDevice(ctx->device));
+  int rc = upload_cloud(ctx, ctx->src0, x, y, z, n, 0.f, k);
+  if (rc) return rc;
+  ctx->have_src = true;
+  ctx->have_assoc = false;
+  rc = copy_src0_to_src(ctx);
+  if (rc) return rc;
+  ICPK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return ICPK_OK;
+}
+
+int icpk_set_target(icpk_ctx* ctx, const float* x, const float* y, const float* z, int32_t n) {
+  return set_target_impl(ctx, x, y, z, n, hipMemcpyHostToDevice);
+}
+int icpk_set_source(icpk_ctx* ctx, const float* x, const float* y, const float* z, int32_t n) {
+  return set_source_impl(ctx, x, y, z, n, hipMemcpyHostToDevice);
+}
+int icpk_set_target_device(icpk_ctx* ctx, const float* x, const float* y, const float* z, int32_t n) {
+  return set_target_impl(ctx, x, y, z, n, hipMemcpyDeviceToDevice);
+}
+int icpk_set_source_device(icpk_ctx* ctx, const float* x, const float* y, const float* z, int32_t n) {
+  return set_source_impl(ctx, x, y, z, n, hipMemcpyDeviceToDevice);
+}
+
+int icpk_reset_source(icpk_ctx* ctx) {
+  if (!ctx) return ICPK_E_ARG;
+  if (!ctx->have_src) return fail(ctx, ICPK_E_NOT_SET, "source cloud not set");
+  ICPK_HIP(ctx, hipSetDevice(ctx->device));
+  int rc = copy_src0_to_src(ctx);
+  if (rc) return rc;
+  ctx->have_assoc = false;
+  ICPK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return ICPK_OK;
+}
+
+int icpk_get_source(icpk_ctx* ctx, float* x, float* y, float* z) {
+  if (!ctx || !x || !y || !z) return ICPK_E_ARG;
+  if (!ctx->have_src) return fail(ctx, ICPK_E_NOT_SET, "source cloud not set");
+  ICPK_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t b = (size_t)ctx->src.n * sizeof(float);
+  if (b) {
+    ICPK_HIP(ctx, hipMemcpyAsync(x, ctx->src.x(), b, hipMemcpyDeviceToHost, ctx->stream));
+    ICPK_HIP(ctx, hipMemcpyAsync(y, ctx->src.y(), b, hipMemcpyDeviceToHost, ctx->stream));
+    ICPK_HIP(ctx, hipMemcpyAsync(z, ctx->src.z(), b, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  ICPK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return ICPK_OK;
+}
+
+int32_t icpk_source_size(const icpk_ctx* ctx) { return ctx && ctx->have_src ? ctx->src0.n : 0; }
+int32_t icpk_target_size(const icpk_ctx* ctx) { return ctx && ctx->have_tgt ? ctx->tgt.n : 0; }
+
+int icpk_get_associations(icpk_ctx* ctx, int32_t* idx_out, float* dist_out) {
+  if (!ctx) return ICPK_E_ARG;
+  if (!ctx->have_assoc) return fail(ctx, ICPK_E_NOT_SET, "no nearest-neighbour sweep has run");
+  ICPK_HIP(ctx, hipSetDevice(ctx->device));
+  const int nq = ctx->src.n;
+  if (nq > 0) {
+    // K2 unpacks (distance, index) keys into the idx/dist planes
+    int rc = enqueue_reduce(ctx, __builtin_inff());
+    if (rc) return rc;
+    if (idx_out)
+      ICPK_HIP(ctx, hipMemcpyAsync(idx_out, ctx->idx, (size_t)nq * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    if (dist_out)
+      ICPK_HIP(ctx, hipMemcpyAsync(dist_out, ctx->dist, (size_t)nq * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  }
+  ICPK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return ICPK_OK;
+}
+
+int icpk_nn(icpk_ctx* ctx, int32_t nn_mode, int32_t* idx_out, float* dist_out) {
+  int rc = check_ready(ctx);
+  if (rc) return rc;
+  ICPK_HIP(ctx, hipSetDevice(ctx->device));
+  rc = enqueue_nn(ctx, nn_mode);
+  if (rc) return rc;
+  if (idx_out || dist_out) return icpk_get_associations(ctx, idx_out, dist_out);
+  ICPK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return ICPK_OK;
+}
+
+int icpk_reduce(icpk_ctx* ctx, float max_dist, double* sums, int64_t* count) {
+  if (!ctx || !sums) return ICPK_E_ARG;
+  if (!ctx->have_assoc) return fail(ctx, ICPK_E_NOT_SET, "no nearest-neighbour sweep has run");
+  ICPK_HIP(ctx, hipSetDevice(ctx->device));
+  if (ctx->src.n == 0) {
+    std::memset(sums, 0, NSUM * sizeof(double));
+    if (count) *count = 0;
+    return ICPK_OK;
+  }
+  int rc = enqueue_reduce(ctx, max_dist);
+  if (rc) return rc;
+  ICPK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  std::memcpy(sums, ctx->red_host, NSUM * sizeof(double));
+  if (count) std::memcpy(count, ctx->red_host + NSUM, sizeof(int64_t));
+  return ICPK_OK;
+}
+
+int icpk_transform_source(icpk_ctx* ctx, const float R[9], const float t[3]) {
+  if (!ctx || !R || !t) return ICPK_E_ARG;
+  if (!ctx->have_src) return fail(ctx, ICPK_E_NOT_SET, "source cloud not set");
+  ICPK_HIP(ctx, hipSetDevice(ctx->device));
+  Rt rt;
+  std::memcpy(rt.R, R, sizeof(rt.R));
+  std::memcpy(rt.t, t, sizeof(rt.t));
+  launch_transform(ctx->src.x(), ctx->src.y(), ctx->src.z(), ctx->src.n, rt, ctx->stream);
+  ICPK_HIP(ctx, hipGetLastError());
+  ctx->have_assoc = false;
+  ICPK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return ICPK_OK;
+}
+
+int icpk_align(icpk_ctx* ctx, const icpk_params* p, float T_out[16], icpk_stats* stats) {
+  if (T_out)
+    for (int k = 0; k < 16; ++k) T_out[k] = (k % 5 == 0) ? 1.f : 0.f;  // identity on failure
+  if (stats) std::memset(stats, 0, sizeof(*stats));
+  if (!ctx || !p || !T_out) return ICPK_E_ARG;
+  if (p->max_iterations < 0 || (p->solve != ICPK_SOLVE_REFERENCE && p->solve != ICPK_SOLVE_KABSCH))
+    return fail(ctx, ICPK_E_ARG, "bad params");
+  int rc = check_ready(ctx);
+  if (rc) {
+    if (stats) stats->status = rc;
+    return rc;
+  }
+  ICPK_HIP(ctx, hipSetDevice(ctx->device));
+  rc = copy_src0_to_src(ctx);
+  if (rc) return rc;
+
+  const bool prof = p->profile != 0;
+  size_t nev = 0;
+  std::vector<size_t> ev_nn, ev_red, ev_tr;  // indices of (start, stop) pairs
+  auto stamp = [&](std::vector<size_t>* list) -> int {
+    if (!prof) return ICPK_OK;
+    hipEvent_t e = get_event(ctx, nev);
+    if (!e) return fail(ctx, ICPK_E_HIP, "hipEventCreate failed");
+    ICPK_HIP(ctx, hipEventRecord(e, ctx->stream));
+    if (list) list->push_back(nev);
+    ++nev;
+    return ICPK_OK;
+  };
+
+  double sums[NSUM];
+  int64_t npairs = 0;
+  float mse = 0.f;
+  int sweeps = 0;
+  auto sweep = [&]() -> int {
+    int r = stamp(&ev_nn);
+    if (r) return r;
+    r = enqueue_nn(ctx, p->nn_mode);
+    if (r) return r;
+    r = stamp(&ev_red);  // end of NN == start of reduce
+    if (r) return r;
+    if (ctx->src.n > 0) {
+      r = enqueue_reduce(ctx, p->max_nn_dist);
+      if (r) return r;
+    }
+    r = stamp(nullptr);  // end of reduce
+    if (r) return r;
+    ICPK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->src.n > 0) {
+      std::memcpy(sums, ctx->red_host, sizeof(sums));
+      std::memcpy(&npairs, ctx->red_host + NSUM, sizeof(int64_t));
+    } else {
+      std::memset(sums, 0, sizeof(sums));
+      npairs = 0;
+    }
+    mse = mse_from(sums, npairs);
+    ++sweeps;
+    log_delta(ctx, ICPK_LOG_NEAREST_NEIGHBOR, (int)npairs);  // icp.cpp:561
+    log_delta(ctx, ICPK_LOG_MSE, (int)npairs);               // icp.cpp:635
+    return ICPK_OK;
+  };
+  auto apply = [&](const float R[9], const float t[3]) -> int {
+    Rt rt;
+    std::memcpy(rt.R, R, sizeof(rt.R));
+    std::memcpy(rt.t, t, sizeof(rt.t));
+    int r = stamp(&ev_tr);
+    if (r) return r;
+    launch_transform(ctx->src.x(), ctx->src.y(), ctx->src.z(), ctx->src.n, rt, ctx->stream);
+    ICPK_HIP(ctx, hipGetLastError());
+    return stamp(nullptr);
+  };
+
+  ctx->log_last = std::chrono::steady_clock::now();
+  rc = sweep();  // icp.cpp:98
+  if (rc) return rc;
+
+  float Trot[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  float offset[3] = {0, 0, 0};
+  double Tk[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+  int status = ICPK_OK;
+  int i = 0;
+  while ((p->fixed_iterations || mse > p->threshold) && i < p->max_iterations) {  // icp.cpp:155
+    if (npairs < p->min_pairs) {  // icp.cpp:163-182: reuse the caller's last motion
+      rc = apply(p->last_rotation, p->last_translation);
+      if (rc) return rc;
+      for (int k = 0; k < 3; ++k) offset[k] = -p->last_translation[k];
+      status = ICPK_W_TOO_FEW_PAIRS;
+      break;
+    }
+    if (p->solve == ICPK_SOLVE_REFERENCE) {
+      float M[9], R[9], Rinv[9], neg[3];
+      for (int k = 0; k < 9; ++k) M[k] = (float)sums[k];  // icp.cpp:212 (CV_32F result)
+      log_delta(ctx, ICPK_LOG_RECONSTRUCT_POINT_CLOUDS, 0);  // icp.cpp:210
+      solve_reference(M, R);                                 // icp.cpp:215-223
+      log_delta(ctx, ICPK_LOG_SVD, 0);                       // icp.cpp:225
+      if (i == 0)
+        std::memcpy(Trot, R, sizeof(Trot));  // icp.cpp:227-229
+      else
+        mul3f(R, Trot, Trot);  // icp.cpp:231-232
+      invert3f(R, Rinv);       // icp.cpp:235
+      for (int k = 0; k < 3; ++k) {
+        offset[k] = (float)(sums[9 + k] / (double)npairs);  // icp.cpp:240 (pre-rotation pairs)
+        neg[k] = -offset[k];
+      }
+      rc = apply(Rinv, neg);  // icp.cpp:236,245
+      if (rc) return rc;
+    } else {
+      double sa[3], sb[3], sab[9], Rd[9], td[3];
+      for (int k = 0; k < 3; ++k) {
+        sa[k] = sums[13 + k];
+        sb[k] = sums[16 + k];
+      }
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) sab[3 * r + c] = sums[3 * c + r];  // sum a_r b_c = M^T
+      log_delta(ctx, ICPK_LOG_RECONSTRUCT_POINT_CLOUDS, 0);
+      solve_kabsch(npairs, sa, sb, sab, Rd, td);
+      log_delta(ctx, ICPK_LOG_SVD, 0);
+      float Rf[9], tf[3];
+      for (int k = 0; k < 9; ++k) Rf[k] = (float)Rd[k];
+      for (int k = 0; k < 3; ++k) tf[k] = (float)td[k];
+      rc = apply(Rf, tf);
+      if (rc) return rc;
+      double Tn[12];
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 4; ++c) {
+          double s = 0;
+          for (int k = 0; k < 3; ++k) s += (double)Rf[3 * r + k] * Tk[4 * k + c];
+          Tn[4 * r + c] = s + (c == 3 ? (double)tf[r] : 0.0);
+        }
+      std::memcpy(Tk, Tn, sizeof(Tk));
+    }
+    log_delta(ctx, ICPK_LOG_ROTATE, 0);  // icp.cpp:250
+    rc = sweep();                        // icp.cpp:255
+    if (rc) return rc;
+    ++i;  // icp.cpp:257
+  }
+  ICPK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+
+  if (p->solve == ICPK_SOLVE_REFERENCE) {
+    for (int r = 0; r < 3; ++r) {
+      for (int c = 0; c < 3; ++c) T_out[4 * r + c] = Trot[3 * r + c];
+      T_out[4 * r + 3] = offset[r];  // icp.cpp:266-268: the LAST offset only
+    }
+  } else {
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 4; ++c) T_out[4 * r + c] = (float)Tk[4 * r + c];
+  }
+  if (stats) {
+    stats->iterations = i;
+    stats->status = status;
+    stats->final_pairs = (int32_t)npairs;
+    stats->final_mse = mse;
+    stats->nn_launches = sweeps;
+    if (prof && nev >= 2) {
+      auto span = [&](size_t a, size_t b) {
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, ctx->events[a], ctx->events[b]);
+        return ms;
+      };
+      for (size_t k : ev_nn) stats->nn_ms_total += span(k, k + 1);
+      for (size_t k : ev_red) stats->reduce_ms_total += span(k, k + 1);
+      for (size_t k : ev_tr) stats->transform_ms_total += span(k, k + 1);
+      stats->total_ms = span(0, nev - 1);
+    }
+  }
+  return status;
+}
+
+int icpk_align_batch(icpk_ctx* ctx, int32_t n_pairs, const icpk_pair* pairs, const icpk_params* p, float* T_out,
+                     icpk_stats* stats) {
+  if (!ctx || n_pairs < 0 || (n_pairs > 0 && (!pairs || !T_out)) || !p) return ICPK_E_ARG;
+  int worst = ICPK_OK;
+  for (int32_t b = 0; b < n_pairs; ++b) {
+    int rc = icpk_set_target(ctx, pairs[b].tx, pairs[b].ty, pairs[b].tz, pairs[b].nt);
+    if (rc == ICPK_OK) rc = icpk_set_source(ctx, pairs[b].sx, pairs[b].sy, pairs[b].sz, pairs[b].ns);
+    if (rc == ICPK_OK)
+      rc = icpk_align(ctx, p, T_out + 16 * (size_t)b, stats ? stats + b : nullptr);
+    else {
+      for (int k = 0; k < 16; ++k) T_out[16 * (size_t)b + k] = (k % 5 == 0) ? 1.f : 0.f;
+      if (stats) {
+        std::memset(stats + b, 0, sizeof(icpk_stats));
+        stats[b].status = rc;
+      }
+    }
+    if (rc < 0 && worst >= 0) worst = rc;
+    if (rc > 0 && worst >= 0 && rc > worst) worst = rc;
+  }
+  return worst;
+}
+
+int icpk_backproject(icpk_ctx* ctx, const uint16_t* depth, int32_t rows, int32_t cols, float fx, float cx,
+                     const float offset[3], int32_t which) {
+  if (!ctx || !depth || rows <= 0 || cols <= 0 || (which != 0 && which != 1) || (int64_t)rows * cols > (1 << 28))
+    return ICPK_E_ARG;
+  ICPK_HIP(ctx, hipSetDevice(ctx->device));
+  const int npix = rows * cols;
+  if (npix > ctx->depth_cap) {
+    if (ctx->depth_dev) ICPK_HIP(ctx, hipFree(ctx->depth_dev));
+    ctx->depth_dev = nullptr;
+    ctx->depth_cap = 0;
+    ICPK_HIP(ctx, hipMalloc((void**)&ctx->depth_dev, (size_t)npix * sizeof(uint16_t)));
+    ctx->depth_cap = npix;
+  }
+  const int nblocks = (npix + 1023) / 1024;
+  if (nblocks + 1 > ctx->bp_counts_cap) {
+    if (ctx->bp_counts) ICPK_HIP(ctx, hipFree(ctx->bp_counts));
+    ctx->bp_counts = nullptr;
+    ctx->bp_counts_cap = 0;
+    ICPK_HIP(ctx, hipMalloc((void**)&ctx->bp_counts, (size_t)(nblocks + 2) * sizeof(int)));
+    ctx->bp_counts_cap = nblocks + 2;
+  }
+  Cloud& c = which == 0 ? ctx->src0 : ctx->tgt;
+  int rc = ensure_cloud(ctx, c, npix);  // worst case: every pixel valid
+  if (rc) return rc;
+  ICPK_HIP(ctx, hipMemcpyAsync(ctx->depth_dev, depth, (size_t)npix * sizeof(uint16_t), hipMemcpyHostToDevice, ctx->stream));
+  const float ox = offset ? offset[0] : 0.f, oy = offset ? offset[1] : 0.f, oz = offset ? offset[2] : 0.f;
+  // the total lands in bp_counts[nblocks + 1] (device) and is read back pinned
+  launch_backproject(ctx->depth_dev, rows, cols, fx, cx, ox, oy, oz, c.x(), c.y(), c.z(), ctx->bp_counts,
+                     ctx->bp_counts + nblocks + 1, ctx->stream);
+  ICPK_HIP(ctx, hipGetLastError());
+  ICPK_HIP(ctx, hipMemcpyAsync(ctx->bp_n_host, ctx->bp_counts + nblocks + 1, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  ICPK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  const int n = *ctx->bp_n_host;
+  c.n = n;
+  const float pad = which == 0 ? 0.f : __builtin_inff();
+  const int padded = round_up(n < 1 ? 1 : n, NN_TILE);
+  launch_fill_f32(c.x() + n, padded - n, pad, ctx->stream);
+  launch_fill_f32(c.y() + n, padded - n, pad, ctx->stream);
+  launch_fill_f32(c.z() + n, padded - n, pad, ctx->stream);
+  ICPK_HIP(ctx, hipGetLastError());
+  ctx->have_assoc = false;
+  if (which == 0) {
+    ctx->have_src = true;
+    rc = copy_src0_to_src(ctx);
+    if (rc) return rc;
+  } else {
+    ctx->have_tgt = true;
+  }
+  ICPK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return n;
+}
+
+/* test hook: icp.cpp:606-620 on n pairs; a and b are host xyz-SoA [3][n] */
+int icpk_pair_distance(icpk_ctx* ctx, const float* a, const float* b, float* out, int32_t n) {
+  if (!ctx || n < 0 || (n > 0 && (!a || !b || !out))) return ICPK_E_ARG;
+  if (n == 0) return ICPK_OK;
+  ICPK_HIP(ctx, hipSetDevice(ctx->device));
+  float *da = nullptr, *db = nullptr, *dout = nullptr;
+  ICPK_HIP(ctx, hipMalloc((void**)&da, (size_t)3 * n * sizeof(float)));
+  ICPK_HIP(ctx, hipMalloc((void**)&db, (size_t)3 * n * sizeof(float)));
+  ICPK_HIP(ctx, hipMalloc((void**)&dout, (size_t)n * sizeof(float)));
+  ICPK_HIP(ctx, hipMemcpyAsync(da, a, (size_t)3 * n * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+  ICPK_HIP(ctx, hipMemcpyAsync(db, b, (size_t)3 * n * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+  launch_pair_distance(da, db, dout, n, ctx->stream);
+  ICPK_HIP(ctx, hipMemcpyAsync(out, dout, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  ICPK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  (void)hipFree(da);
+  (void)hipFree(db);
+  (void)hipFree(dout);
+  return ICPK_OK;
+}
+
+void icpk_make_rotation_matrix(float x, float y, float z, float out[9]) { make_rotation_matrix(x, y, z, out); }
+void icpk_matrix_to_quaternion(const float m[9], float q[4]) { matrix_to_quaternion(m, q); }
+void icpk_quaternion_to_euler(const float q[4], float e[3]) { quaternion_to_euler(q, e); }
+void icpk_solve_reference(const float M[9], float R[9]) { solve_reference(M, R); }
+void icpk_solve_kabsch(int64_t n, const double sa[3], const double sb[3], const double sab[9], double R[9], double t[3]) {
+  solve_kabsch(n, sa, sb, sab, R, t);
+}
+
+}  // extern "C"

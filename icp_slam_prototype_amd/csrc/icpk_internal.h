@@ -1,0 +1,75 @@
+// icpk_internal.h -- shared between the host side (icpk_api.cpp) and the HIP
+// kernels.  Not part of the ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace icpk {
+
+// ---- K1 geometry ----------------------------------------------------------
+// One query per lane, 256 lanes (4 wave64) per workgroup; the target cloud is
+// streamed through LDS in tiles of NN_TILE points (3 planes x 4 KiB).  Target
+// planes are padded to a multiple of NN_TILE with +inf (never selected).
+constexpr int NN_THREADS = 256;
+constexpr int NN_TILE = 1024;
+static_assert(NN_TILE == 4 * NN_THREADS, "one float4 per lane per plane per tile");
+
+// (distance bits << 32) | index: for non-negative floats the bit pattern is
+// monotone, so an unsigned 64-bit min is the lexicographic (distance, index)
+// min -- independent of the order target chunks are merged in.
+typedef unsigned long long nn_key_t;
+constexpr nn_key_t NN_KEY_INIT = ~0ull;
+
+struct NnArgs {
+  const float* qx;
+  const float* qy;
+  const float* qz;
+  int nq;
+  const float* tx;
+  const float* ty;
+  const float* tz;
+  int nt_pad;           // multiple of NN_TILE
+  int tiles_per_chunk;  // target tiles handled by one workgroup
+  nn_key_t* best;       // [nq], pre-set to NN_KEY_INIT
+};
+
+struct Rt {
+  float R[9];
+  float t[3];
+};
+
+constexpr int NSUM = 19;
+constexpr int RED_THREADS = 256;
+constexpr int RED_MAX_BLOCKS = 256;
+
+inline int red_blocks(int n) {
+  int b = (n + RED_THREADS - 1) / RED_THREADS;
+  if (b < 1) b = 1;
+  if (b > RED_MAX_BLOCKS) b = RED_MAX_BLOCKS;
+  return b;
+}
+
+// kernels_nn.hip
+void launch_fill_u64(nn_key_t* p, int n, nn_key_t v, hipStream_t s);
+void launch_nn_exact(const NnArgs& a, hipStream_t s);
+void launch_nn_filtered(const NnArgs& a, const nn_key_t* seed, hipStream_t s);
+void launch_pair_distance(const float* a, const float* b, float* out, int n, hipStream_t s);
+
+// kernels_reduce.hip
+// partial: [RED_MAX_BLOCKS][NSUM] doubles, pcount: [RED_MAX_BLOCKS] ints,
+// out: NSUM doubles followed by one int64 count (20 x 8 bytes).
+void launch_assoc_reduce(const nn_key_t* best, const float* ax, const float* ay, const float* az, int nq,
+                         const float* tx, const float* ty, const float* tz, float max_dist, int32_t* idx_out,
+                         float* dist_out, double* partial, int* pcount, double* out, hipStream_t s);
+
+// kernels_transform.hip
+void launch_transform(float* x, float* y, float* z, int n, const Rt& rt, hipStream_t s);
+void launch_fill_f32(float* p, int n, float v, hipStream_t s);
+
+// kernels_backproject.hip
+// counts: [ceil(npix/1024)+1] ints scratch.  Returns nothing; *n_out (device)
+// receives the number of points.
+void launch_backproject(const uint16_t* depth, int rows, int cols, float fx, float cx, float ox, float oy, float oz,
+                        float* x, float* y, float* z, int* block_counts, int* n_out, hipStream_t s);
+
+}  // namespace icpk

@@ -1,0 +1,98 @@
+// kernels_reduce.hip -- K2: masked reduction over the associations of one sweep.
+//
+// Folds into one pass what the reference does with four O(N) loops:
+//   icp.cpp:186-200  association split + N x 3 matrix export
+//   icp.cpp:212      M = previousMat.t() * dataMat      (9 sums, M[r][c] = sum b_r a_c)
+//   icp.cpp:314-344  calculateOffset                    (3 sums of (float)(a - b))
+//   icp.cpp:622-638  meanSquareError                    (1 sum of distances, count)
+// plus sum a / sum b (6) for the centred Kabsch flavour (rigid_transform_3D.py:14-20).
+//
+// Summation order is the canonical tree of include/icpk.h (ICPK_RED_*): double
+// accumulators, wave64 xor butterfly via __shfl_xor, fixed wave and block
+// order -- no atomics, so results are bit-reproducible and equal to the
+// oracle's orc_sums_canonical.
+#include "icpk_internal.h"
+
+namespace icpk {
+
+__global__ __launch_bounds__(RED_THREADS) void assoc_reduce_kernel(
+    const nn_key_t* __restrict__ best, const float* __restrict__ ax, const float* __restrict__ ay,
+    const float* __restrict__ az, int nq, const float* __restrict__ tx, const float* __restrict__ ty,
+    const float* __restrict__ tz, float max_dist, int32_t* __restrict__ idx_out, float* __restrict__ dist_out,
+    double* __restrict__ partial, int* __restrict__ pcount) {
+  const int tid = threadIdx.x;
+  const int P = gridDim.x * RED_THREADS;
+  double v[NSUM];
+#pragma unroll
+  for (int s = 0; s < NSUM; ++s) v[s] = 0.0;
+  int cnt = 0;
+
+  for (int i = blockIdx.x * RED_THREADS + tid; i < nq; i += P) {
+    const nn_key_t key = best[i];
+    const float d = __uint_as_float((unsigned)(key >> 32));
+    const int j = (int)(unsigned)(key & 0xffffffffu);
+    idx_out[i] = j;
+    dist_out[i] = d;
+    if (d < max_dist) {  // icp.cpp:553 (false for NaN)
+      const float a0 = ax[i], a1 = ay[i], a2 = az[i];
+      const float b0 = tx[j], b1 = ty[j], b2 = tz[j];
+      const double da0 = a0, da1 = a1, da2 = a2, db0 = b0, db1 = b1, db2 = b2;
+      v[0] += db0 * da0; v[1] += db0 * da1; v[2] += db0 * da2;
+      v[3] += db1 * da0; v[4] += db1 * da1; v[5] += db1 * da2;
+      v[6] += db2 * da0; v[7] += db2 * da1; v[8] += db2 * da2;
+      v[9] += (double)(a0 - b0);
+      v[10] += (double)(a1 - b1);
+      v[11] += (double)(a2 - b2);
+      v[12] += (double)d;
+      v[13] += da0; v[14] += da1; v[15] += da2;
+      v[16] += db0; v[17] += db1; v[18] += db2;
+      ++cnt;
+    }
+  }
+
+  // wave64 butterfly: every lane ends with the same value; order 32,16,...,1
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+#pragma unroll
+    for (int s = 0; s < NSUM; ++s) v[s] += __shfl_xor(v[s], m, 64);
+    cnt += __shfl_xor(cnt, m, 64);
+  }
+
+  __shared__ double ws[RED_THREADS / 64][NSUM];
+  __shared__ int wc[RED_THREADS / 64];
+  const int wave = tid >> 6, lane = tid & 63;
+  if (lane == 0) {
+#pragma unroll
+    for (int s = 0; s < NSUM; ++s) ws[wave][s] = v[s];
+    wc[wave] = cnt;
+  }
+  __syncthreads();
+  if (tid < NSUM) partial[blockIdx.x * NSUM + tid] = ((ws[0][tid] + ws[1][tid]) + ws[2][tid]) + ws[3][tid];
+  if (tid == NSUM) pcount[blockIdx.x] = wc[0] + wc[1] + wc[2] + wc[3];
+}
+
+// blocks are added in block order by one lane per quantity
+__global__ void reduce_final_kernel(const double* __restrict__ partial, const int* __restrict__ pcount, int nblocks,
+                                    double* __restrict__ out) {
+  const int tid = threadIdx.x;
+  if (tid < NSUM) {
+    double t = 0.0;
+    for (int b = 0; b < nblocks; ++b) t += partial[b * NSUM + tid];
+    out[tid] = t;
+  } else if (tid == NSUM) {
+    long long c = 0;
+    for (int b = 0; b < nblocks; ++b) c += pcount[b];
+    reinterpret_cast<long long*>(out)[NSUM] = c;
+  }
+}
+
+void launch_assoc_reduce(const nn_key_t* best, const float* ax, const float* ay, const float* az, int nq,
+                         const float* tx, const float* ty, const float* tz, float max_dist, int32_t* idx_out,
+                         float* dist_out, double* partial, int* pcount, double* out, hipStream_t s) {
+  const int B = red_blocks(nq);
+  hipLaunchKernelGGL(assoc_reduce_kernel, dim3(B), dim3(RED_THREADS), 0, s, best, ax, ay, az, nq, tx, ty, tz,
+                     max_dist, idx_out, dist_out, partial, pcount);
+  hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(64), 0, s, partial, pcount, B, out);
+}
+
+}  // namespace icpk

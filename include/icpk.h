@@ -1,0 +1,201 @@
+/*
+ * icpk.h -- C ABI of libicpk.so: the MI355X (gfx950) implementation of the ICP
+ * inner loop of BenniG123/icp-slam-prototype.
+ *
+ * This is the drop-in boundary.  The reference has no
+ * FFI: its hot path is C++ called in-process.  Each entry point below names the
+ * reference code it replaces ("file:line" relative to the reference checkout).
+ * Plain pointers and sizes only; no C++/torch types; nothing throws across the
+ * boundary.  All functions return an int status (ICPK_OK == 0, negative =
+ * error, positive = completed with a documented fallback) unless noted.
+ *
+ * There is NO CPU fallback: icpk_create fails with ICPK_E_NO_DEVICE when no HIP
+ * device is usable.
+ *
+ * Data layout: point clouds are xyz structure-of-arrays (three float planes),
+ * replacing the reference's 16-byte AoS color_point_t (pointcloud.hpp:13-19);
+ * colour is dropped because COLOR_WEIGHT is 0.0f (icp.hpp:6).
+ */
+#ifndef ICPK_H
+#define ICPK_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ICPK_VERSION_STRING "icpk 0.1.0 (gfx950)"
+
+/* ---- status codes -------------------------------------------------------- */
+#define ICPK_OK 0
+#define ICPK_W_TOO_FEW_PAIRS 1   /* < min_pairs associations: fell back to the  \
+                                    caller's last motion (icp.cpp:163-182)      */
+#define ICPK_E_ARG (-1)          /* null pointer / negative size / bad enum     */
+#define ICPK_E_EMPTY_TARGET (-2) /* icp.cpp:572 dereferences begin(): UB there  */
+#define ICPK_E_HIP (-3)          /* a HIP runtime call failed (see last_error)  */
+#define ICPK_E_NOT_SET (-4)      /* source or target not uploaded yet           */
+#define ICPK_E_NO_DEVICE (-5)    /* no usable HIP device: no CPU fallback       */
+
+/* ---- reference constants (defaults of icpk_default_params) --------------- */
+#define ICPK_MAX_NN_DISTANCE 0.75f          /* icp.hpp:8  MAX_NN_COLOR_DISTANCE    */
+#define ICPK_MAX_NN_KEYPOINT_DISTANCE 0.1f  /* icp.hpp:10 MAX_NN_KEYPOINT_DISTANCE */
+#define ICPK_DEFAULT_MAX_ITERATIONS 16      /* SLAM.cpp:277                        */
+#define ICPK_DEFAULT_THRESHOLD 0.0001f      /* SLAM.cpp:277                        */
+#define ICPK_MIN_PAIRS 3                    /* icp.cpp:163                         */
+#define ICPK_FX 468.60f                     /* pointcloud.hpp:7                    */
+#define ICPK_CX 318.27f                     /* pointcloud.hpp:9                    */
+#define ICPK_DEPTH_SCALE 5000.0f            /* pointcloud.cpp:37                   */
+
+/* solve flavours */
+#define ICPK_SOLVE_REFERENCE 0 /* bug-for-bug icp.cpp:199-246 (un-centred moment,    \
+                                  R = V U^T, column-2 flip, mean-difference offset)  */
+#define ICPK_SOLVE_KABSCH 1    /* centred Kabsch, rigid_transform_3D.py:9-40         */
+
+/* nearest-neighbour kernel selection */
+#define ICPK_NN_EXACT 0    /* literal double-precision distance per pair             */
+#define ICPK_NN_FILTERED 1 /* seeded fp32 filter + exact re-evaluation; same results */
+
+/* log keys mirrored from SLAM.hpp:4-13 for the optional callback */
+#define ICPK_LOG_NEAREST_NEIGHBOR 0
+#define ICPK_LOG_RECONSTRUCT_POINT_CLOUDS 5
+#define ICPK_LOG_SVD 6
+#define ICPK_LOG_ROTATE 7
+#define ICPK_LOG_MSE 8
+
+/* Canonical reduction geometry (part of the ABI: it fixes the summation order
+ * of icpk_reduce so results are bit-reproducible and checkable): 256-thread
+ * blocks, B = clamp(ceil(n/256), 1, 256) blocks, thread g sums elements
+ * g, g+256B, ... in order; 64-lane xor butterfly; ((w0+w1)+w2)+w3; blocks in
+ * order. */
+#define ICPK_RED_THREADS 256
+#define ICPK_RED_MAX_BLOCKS 256
+#define ICPK_NSUM 19 /* [0..8] M[r][c]=sum b_r a_c, [9..11] sum (float)(a-b), \
+                        [12] sum dist, [13..15] sum a, [16..18] sum b          */
+
+typedef struct icpk_ctx icpk_ctx; /* opaque: owns device buffers + one HIP stream */
+
+typedef struct icpk_params {
+  int32_t max_iterations;   /* SLAM.cpp:277 (16)                                  */
+  float threshold;          /* SLAM.cpp:277 (1e-4): loop while mse > threshold    */
+  float max_nn_dist;        /* icp.hpp:8 (0.75) or icp.hpp:10 (0.1)               */
+  int32_t min_pairs;        /* icp.cpp:163 (3)                                    */
+  int32_t solve;            /* ICPK_SOLVE_*                                       */
+  int32_t fixed_iterations; /* 1: ignore threshold, run max_iterations (bench)    */
+  int32_t nn_mode;          /* ICPK_NN_*                                          */
+  int32_t profile;          /* 1: bracket every kernel with HIP events -> stats   */
+  float last_rotation[9];    /* caller's previous motion, icp.cpp:23,176          */
+  float last_translation[3]; /* icp.cpp:25,177                                    */
+} icpk_params;
+
+typedef struct icpk_stats {
+  int32_t iterations;  /* completed loop bodies (icp.cpp:257)                     */
+  int32_t status;      /* same value icpk_align returned                          */
+  int32_t final_pairs; /* associations after the last sweep                       */
+  float final_mse;     /* meanSquareError of the last sweep (icp.cpp:264)         */
+  int32_t nn_launches; /* NN sweeps launched (= iterations + 1)                   */
+  int32_t reserved;
+  /* device times measured with HIP events on the context's stream; filled only
+   * when params.profile != 0 */
+  float nn_ms_total;        /* sum over sweeps of the NN kernel(s)                */
+  float reduce_ms_total;    /* association reduce kernels                         */
+  float transform_ms_total; /* point transform kernels                            */
+  float total_ms;           /* first launch to last completion                    */
+} icpk_stats;
+
+/* One frame pair for icpk_align_batch (host pointers, SoA). */
+typedef struct icpk_pair {
+  const float *sx, *sy, *sz;
+  int32_t ns;
+  const float *tx, *ty, *tz;
+  int32_t nt;
+} icpk_pair;
+
+/* same shape as logDeltaTime(int logKey, int quantity) (SLAM.hpp:30,
+ * SLAM.cpp:493-510) plus the elapsed microseconds the reference computes
+ * internally */
+typedef void (*icpk_log_fn)(int key, int quantity, double usec, void *user);
+
+/* ---- lifetime ------------------------------------------------------------ */
+const char *icpk_version(void);
+int icpk_create(icpk_ctx **out, int device_id);
+void icpk_destroy(icpk_ctx *ctx);
+const char *icpk_last_error(const icpk_ctx *ctx);
+void icpk_default_params(icpk_params *p);
+int icpk_set_log_callback(icpk_ctx *ctx, icpk_log_fn fn, void *user);
+/* the HIP stream all work of this context is enqueued on (hipStream_t) */
+void *icpk_stream(icpk_ctx *ctx);
+
+/* ---- clouds: replaces the PointCloud containers built at icp.cpp:38-39 ---- */
+/* host pointers (copied; caller keeps ownership) */
+int icpk_set_target(icpk_ctx *ctx, const float *x, const float *y, const float *z, int32_t n);
+int icpk_set_source(icpk_ctx *ctx, const float *x, const float *y, const float *z, int32_t n);
+/* device pointers on the context's device (copied device-to-device) */
+int icpk_set_target_device(icpk_ctx *ctx, const float *dx, const float *dy, const float *dz, int32_t n);
+int icpk_set_source_device(icpk_ctx *ctx, const float *dx, const float *dy, const float *dz, int32_t n);
+/* working copy of the source <- the cloud last given to icpk_set_source*     */
+int icpk_reset_source(icpk_ctx *ctx);
+/* current (transformed) source, to host */
+int icpk_get_source(icpk_ctx *ctx, float *x, float *y, float *z);
+int32_t icpk_source_size(const icpk_ctx *ctx);
+int32_t icpk_target_size(const icpk_ctx *ctx);
+
+/* ---- the three steps of one iteration ------------------------------------ */
+/* icp.cpp:541-563 findGlobalNearestNeighborAssociations + :566-593
+ * getNearestPoint + :606-620 distance.  For every source point the index of
+ * the target element the reference scan would copy (strict '<' on the float
+ * distance, lowest index wins ties) and that distance.  Outputs may be NULL
+ * (results stay on the device for icpk_reduce).  The `d < max` acceptance of
+ * icp.cpp:553 is applied by the consumers, not here. */
+int icpk_nn(icpk_ctx *ctx, int32_t nn_mode, int32_t *idx_out, float *dist_out);
+/* icp.cpp:186-212 (association split + cross moment), :314-344
+ * (calculateOffset sums), :622-638 (meanSquareError sum), in one pass over the
+ * associations of the last icpk_nn, canonical order.  sums: ICPK_NSUM doubles. */
+int icpk_reduce(icpk_ctx *ctx, float max_dist, double *sums, int64_t *count);
+/* pointcloud.cpp:321-346 rotate + :349-359 translate:
+ * p <- fl32(fl32(R p) + t), R row-major, applied to the working source. */
+int icpk_transform_source(icpk_ctx *ctx, const float R[9], const float t[3]);
+/* associations of the last sweep (device -> host) */
+int icpk_get_associations(icpk_ctx *ctx, int32_t *idx_out, float *dist_out);
+
+/* ---- whole loop: replaces icp.cpp:98-268 --------------------------------- */
+/* Starts from the source as uploaded (icpk_reset_source), leaves the aligned
+ * source on the device.  T_out: row-major 4x4, same content as the CV_32FC1
+ * matrix icp::getTransformation returns (icp.cpp:29,227-233,266-268) with row
+ * 3 = (0,0,0,1) instead of uninitialised memory.  stats may be NULL. */
+int icpk_align(icpk_ctx *ctx, const icpk_params *p, float T_out[16], icpk_stats *stats);
+/* frame-batch mode: n_pairs independent pairs, one after the
+ * other on this context's device; T_out n_pairs x 16, stats n_pairs (or NULL).
+ * Returns the first negative status, else the max status. */
+int icpk_align_batch(icpk_ctx *ctx, int32_t n_pairs, const icpk_pair *pairs,
+                     const icpk_params *p, float *T_out, icpk_stats *stats);
+
+/* ---- front end -------------------------------------- */
+/* pointcloud.cpp:19-58 without the rand()%40 subsample: row-major back-
+ * projection of a rows x cols uint16 depth image (host pointer) into the
+ * source (which = 0) or target (which = 1) cloud, adding `offset` to every
+ * coordinate afterwards (PointCloud::translate(cameraPosition), icp.cpp:71).
+ * Returns the number of points (>= 0) or a negative status. */
+int icpk_backproject(icpk_ctx *ctx, const uint16_t *depth, int32_t rows, int32_t cols,
+                     float fx, float cx, const float offset[3], int32_t which);
+
+/* ---- test hook ------------------------------------------------------------ */
+/* icp.cpp:606-620 distance(color_point_t, color_point_t) evaluated on the
+ * device for n pairs; a and b are host xyz-SoA arrays [3][n].  Lets the parity
+ * tests check the float/double/sqrt sequence bit for bit on its own. */
+int icpk_pair_distance(icpk_ctx *ctx, const float *a, const float *b, float *out, int32_t n);
+
+/* ---- small host helpers restated from the reference (no device work) ----- */
+void icpk_make_rotation_matrix(float x_deg, float y_deg, float z_deg, float out[9]); /* icp.cpp:640-653      */
+void icpk_matrix_to_quaternion(const float m[9], float q_wxyz[4]);                 /* quaternion.cpp:23-79 */
+void icpk_quaternion_to_euler(const float q_wxyz[4], float e_deg[3]);              /* SLAM.cpp:613-636     */
+/* host solve exposed for testing: reference flavour from the float moment,
+ * Kabsch flavour from raw sums (n, sum a, sum b, sum a b^T) */
+void icpk_solve_reference(const float M[9], float R[9]);                           /* icp.cpp:215-223      */
+void icpk_solve_kabsch(int64_t n, const double sa[3], const double sb[3],
+                       const double sab[9], double R[9], double t[3]);             /* rigid_transform_3D.py:9-40 */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ICPK_H */

@@ -1,0 +1,304 @@
+"""Parity tests proper: the HIP path, called through the C ABI (ctypes), against
+the oracle on the same seeded inputs.  Integer/index work must be bit-exact;
+the whole-loop transform must be within 1e-5 Frobenius (north_star), and is in
+fact bit-identical to the oracle's canonical-order mode.
+
+/root/reference does not exist on the GPU box: nothing here reads it.
+"""
+import numpy as np
+import pytest
+
+from icp_slam_prototype_amd import binding, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = binding.Context(0)
+    yield c
+    c.close()
+
+
+# ----------------------------------------------------------------- distance --
+def test_pair_distance_bits(ctx, oracle):
+    """icp.cpp:606-620 on the device vs the oracle, including the correctly
+    rounded float sqrt, tiny/huge magnitudes, zero distance and inf padding."""
+    rng = np.random.default_rng(0)
+    n = 200000
+    a = rng.uniform(-4, 4, (3, n)).astype(np.float32)
+    b = (a + rng.normal(0, 1, (3, n)) * 10.0 ** rng.uniform(-6, 1, (1, n))).astype(np.float32)
+    a[:, :10] = b[:, :10]                       # exact zero distance
+    b[:, 10:20] = np.float32(np.inf)            # padded targets
+    a[:, 20:30] *= np.float32(1e-18)            # denormal-range squares
+    b[:, 20:30] *= np.float32(1e-18)
+    a[:, 30:40] *= np.float32(1e15)             # large
+    got = ctx.pair_distance(a, b)
+    dx = (a - b).astype(np.float32)
+    s = (dx[0].astype(np.float64) ** 2 + dx[1].astype(np.float64) ** 2) + dx[2].astype(np.float64) ** 2
+    with np.errstate(over="ignore", invalid="ignore"):
+        want = np.sqrt(s.astype(np.float32))
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    for i in (0, 15, 25, 35, 100, 5000):
+        o = oracle.distance(a[:, i], b[:, i])
+        assert got[i] == o or (np.isinf(got[i]) and np.isinf(o))
+
+
+# ----------------------------------------------------------------------- NN --
+def _check_nn(ctx, oracle, src, tgt):
+    ctx.set_target(tgt)
+    ctx.set_source(src)
+    idx, dist = ctx.nn()
+    oidx, odist = oracle.nn_bruteforce(src, tgt, threads=oracle.max_threads())
+    assert np.array_equal(idx, oidx)
+    assert np.array_equal(dist.view(np.uint32), odist.view(np.uint32))
+    return idx, dist
+
+
+@pytest.mark.parametrize("nq,nt", [(1, 1), (1, 5), (5, 1), (63, 65), (256, 1024), (257, 1025), (1000, 3000),
+                                   (3000, 1000), (4096, 4096)])
+def test_nn_random_sizes(ctx, oracle, nq, nt):
+    rng = np.random.default_rng(nq * 7919 + nt)
+    src = (rng.uniform(-2, 2, (3, nq)) + 5).astype(np.float32)
+    tgt = (rng.uniform(-2, 2, (3, nt)) + 5).astype(np.float32)
+    _check_nn(ctx, oracle, src, tgt)
+
+
+def test_nn_lattice_ties_lowest_index(ctx, oracle):
+    """Tie-heavy wall: many queries have >= 2 targets at the
+    identical float distance; the lowest index must win, also across LDS tiles
+    and target chunks merged by the 64-bit atomic min."""
+    p = synth.lattice_wall(60, 80)  # 4800 targets: 5 tiles
+    idx, dist = _check_nn(ctx, oracle, p["source"], p["target"])
+    # duplicate the target cloud: every point now has an exact twin 4800 later
+    tgt2 = np.concatenate([p["target"], p["target"]], axis=1)
+    idx2, _ = _check_nn(ctx, oracle, p["source"], tgt2)
+    assert (idx2 < 4800).all() and np.array_equal(idx2, idx)
+
+
+def test_nn_sqrt_collision_classes(ctx, oracle):
+    """Targets whose squared distances differ by one ulp but whose float sqrt is
+    identical: the reference compares the sqrt, so the EARLIER index wins even
+    though its squared distance is larger."""
+    # query at origin, targets on the x axis: d = x exactly, xyz = x*x
+    base = np.float32(1.5)
+    xs = []
+    v = base
+    for _ in range(64):
+        xs.append(v)
+        v = np.nextafter(v, np.float32(2))
+    xs = np.array(xs[::-1], np.float32)  # descending: later targets are nearer
+    tgt = np.stack([xs, np.zeros_like(xs), np.zeros_like(xs)])
+    src = np.zeros((3, 1), np.float32)
+    _check_nn(ctx, oracle, src, tgt)
+    # squared distances 1 ulp apart mapping to the same sqrt: use y so that xyz varies finely
+    q = np.zeros((3, 1), np.float32)
+    ys = np.sqrt(np.float32(2.0) + np.arange(64, dtype=np.float32) * np.float32(2.4e-7))[::-1].copy()
+    tgt = np.stack([np.zeros_like(ys), ys, np.zeros_like(ys)]).astype(np.float32)
+    idx, dist = _check_nn(ctx, oracle, q, tgt)
+    d_all = np.array([oracle.distance(q[:, 0], tgt[:, j]) for j in range(tgt.shape[1])])
+    assert (d_all == d_all.min()).sum() >= 2  # the collision really occurs
+    assert idx[0] == np.flatnonzero(d_all == d_all.min())[0]
+
+
+def test_nn_config1_10k(ctx, oracle):
+    p = synth.frustum_pair(10000, seed=1)
+    _check_nn(ctx, oracle, p["source"], p["target"])
+
+
+def test_nn_kinect_quarter_frame(ctx, oracle):
+    """Config-2-shaped data (ray-cast room, 30% valid, world offset 5,5,5) at a
+    size the oracle finishes in seconds."""
+    p = synth.kinect_pair(rows=240, cols=320, seed=2)
+    assert 20000 < p["source"].shape[1] < 26000
+    _check_nn(ctx, oracle, p["source"], p["target"])
+
+
+def test_nn_errors(ctx):
+    ctx.set_source(np.zeros((3, 4), np.float32))
+    ctx.set_target(np.zeros((3, 0), np.float32))
+    with pytest.raises(binding.IcpkError) as e:
+        ctx.nn()
+    assert e.value.code == binding.E_EMPTY_TARGET
+    T, st, rc = None, None, None
+    with pytest.raises(binding.IcpkError) as e:
+        ctx.align()
+    assert e.value.code == binding.E_EMPTY_TARGET
+    c2 = binding.Context(0)
+    with pytest.raises(binding.IcpkError) as e:
+        c2.nn()
+    assert e.value.code == binding.E_NOT_SET
+    c2.close()
+    # empty source is legal: nothing to associate
+    ctx.set_target(np.ones((3, 7), np.float32))
+    ctx.set_source(np.zeros((3, 0), np.float32))
+    idx, dist = ctx.nn()
+    assert idx.size == 0
+    sums, cnt = ctx.reduce()
+    assert cnt == 0 and not sums.any()
+    T, st, rc = ctx.align()
+    assert rc == 0 and st.iterations == 0 and np.array_equal(T, np.eye(4, dtype=np.float32))
+
+
+# ------------------------------------------------------------------- reduce --
+@pytest.mark.parametrize("n,maxd", [(100, 0.75), (5000, 0.75), (5000, 0.05), (70000, 0.75)])
+def test_reduce_bit_exact_vs_oracle_canonical(ctx, oracle, n, maxd):
+    rng = np.random.default_rng(n)
+    tgt = (rng.uniform(-2, 2, (3, 3000)) + 5).astype(np.float32)
+    src = (tgt[:, rng.integers(0, 3000, n)] + rng.normal(0, 0.03, (3, n))).astype(np.float32)
+    ctx.set_target(tgt)
+    ctx.set_source(src)
+    idx, dist = ctx.nn()
+    sums, cnt = ctx.reduce(maxd)
+    osums, ocnt = oracle.sums_canonical(src, tgt, idx, dist, maxd)
+    assert cnt == ocnt and 0 < cnt
+    if maxd < 0.5:
+        assert cnt < n
+    assert np.array_equal(sums.view(np.uint64), osums.view(np.uint64))
+    # and the reference-order (sequential float) quantities agree to tolerance
+    off, _ = oracle.calculate_offset_seq(src, tgt, idx, dist, maxd)
+    assert np.allclose(sums[9:12] / cnt, off, rtol=0, atol=2e-6)
+    M, _ = oracle.cross_moment_seq(src, tgt, idx, dist, maxd)
+    assert np.allclose(sums[:9].reshape(3, 3), M, rtol=1e-6)
+
+
+# ---------------------------------------------------------------- transform --
+def test_transform_bit_exact(ctx, oracle):
+    rng = np.random.default_rng(5)
+    for n in (1, 3, 1023, 1024, 1025, 10000):
+        src = (rng.uniform(-3, 3, (3, n)) + 5).astype(np.float32)
+        ctx.set_source(src)
+        R = oracle.make_rotation_matrix(3, -2, 1)
+        t = np.array([0.1, -0.2, 0.3], np.float32)
+        ctx.transform_source(R, t)
+        got = ctx.get_source()
+        want = oracle.transform_points(src, R, t)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+        ctx.transform_source(oracle.inv3(R), -t)
+        want2 = oracle.transform_points(want, oracle.inv3(R), -t)
+        assert np.array_equal(ctx.get_source(), want2)
+        ctx.reset_source()
+        assert np.array_equal(ctx.get_source(), src)
+
+
+# ---------------------------------------------------------------- full loop --
+def _align_both(ctx, oracle, src, tgt, **kw):
+    ctx.set_target(tgt)
+    ctx.set_source(src)
+    p = binding.default_params(**kw)
+    T, st, rc = ctx.align(p)
+    o = oracle.align(src, tgt, max_iterations=p.max_iterations, threshold=p.threshold, max_nn_dist=p.max_nn_dist,
+                     min_pairs=p.min_pairs, solve=p.solve, sum_order=1, fixed_iterations=bool(p.fixed_iterations),
+                     threads=oracle.max_threads(), last_rotation=np.array(p.last_rotation, np.float32),
+                     last_translation=np.array(p.last_translation, np.float32))
+    return T, st, rc, o
+
+
+@pytest.mark.parametrize("solve", [binding.SOLVE_REFERENCE, binding.SOLVE_KABSCH])
+def test_align_matches_oracle_config1(ctx, oracle, solve):
+    """BASELINE config 1 (10k points, 5 degree rotation), both solve flavours."""
+    p = synth.frustum_pair(10000, seed=1)
+    src, tgt = p["source"] + np.float32(5), p["target"] + np.float32(5)
+    T, st, rc, o = _align_both(ctx, oracle, src, tgt, solve=solve, max_iterations=12, fixed_iterations=1)
+    assert rc == o["status"] == 0 and st.iterations == o["iterations"] == 12
+    assert np.linalg.norm(T.astype(np.float64) - o["T"].astype(np.float64)) < 1e-5  # Frobenius, north_star
+    assert st.final_pairs == o["final_pairs"]
+    idx, dist = ctx.get_associations()
+    assert np.array_equal(idx, o["idx"])  # correspondences of the last sweep, bit-exact
+    assert np.array_equal(dist.view(np.uint32), o["dist"].view(np.uint32))
+    assert np.array_equal(ctx.get_source().view(np.uint32), o["src_out"].view(np.uint32))
+    assert np.float32(st.final_mse) == o["final_mse"]
+
+
+def test_align_kabsch_recovers_known_motion(ctx):
+    p = synth.frustum_pair(10000, seed=1)
+    ctx.set_target(p["target"])
+    ctx.set_source(p["source"])
+    T, st, rc = ctx.align(solve=binding.SOLVE_KABSCH, max_iterations=40, threshold=0.0)
+    c = p["target"].astype(np.float64).mean(axis=1)
+    R_inv = p["R_true"].T
+    t_inv = -R_inv @ (p["t_true"] + c - p["R_true"] @ c)
+    assert np.linalg.norm(T[:3, :3] - R_inv) < 1e-5
+    assert np.linalg.norm(T[:3, 3] - t_inv) < 1e-4
+    idx, _ = ctx.get_associations()
+    assert np.array_equal(idx, np.arange(10000))
+
+
+def test_align_kinect_quarter_frame_reference_flavour(ctx, oracle):
+    p = synth.kinect_pair(rows=240, cols=320, seed=2)
+    T, st, rc, o = _align_both(ctx, oracle, p["source"], p["target"], solve=binding.SOLVE_REFERENCE,
+                               max_iterations=4, fixed_iterations=1)
+    assert st.iterations == o["iterations"] == 4
+    assert np.linalg.norm(T.astype(np.float64) - o["T"].astype(np.float64)) < 1e-5
+    idx, dist = ctx.get_associations()
+    assert np.array_equal(idx, o["idx"])
+    # reference-order summation (sequential float) stays within the tolerance too
+    o2 = oracle.align(p["source"], p["target"], max_iterations=4, solve=0, sum_order=0, fixed_iterations=True,
+                      threads=oracle.max_threads())
+    assert np.linalg.norm(T.astype(np.float64) - o2["T"].astype(np.float64)) < 1e-5
+
+
+def test_align_threshold_exit_fallback_and_idempotence(ctx, oracle):
+    p = synth.frustum_pair(800, seed=5, rot_deg=(0, 0.5, 0), shift=(0.002, 0, 0))
+    T, st, rc, o = _align_both(ctx, oracle, p["source"], p["target"], solve=binding.SOLVE_KABSCH)
+    assert st.iterations == o["iterations"] < 16 and st.final_mse <= 1e-4
+    T2, st2, _ = ctx.align(solve=binding.SOLVE_KABSCH)  # align restarts from the uploaded source
+    assert np.array_equal(T, T2) and st2.iterations == st.iterations
+    far = p["source"] + np.float32(100)
+    far[:, :2] = p["target"][:, :2] + np.float32(0.05)
+    lt = np.array([1, 2, 3], np.float32)
+    T, st, rc, o = _align_both(ctx, oracle, far, p["target"], last_translation=lt)
+    assert rc == binding.W_TOO_FEW_PAIRS and o["status"] == 1 and st.iterations == 0 and st.final_pairs == 2
+    assert np.array_equal(T, o["T"]) and np.array_equal(T[:3, 3], -lt)
+    assert np.array_equal(ctx.get_source(), o["src_out"])
+
+
+def test_align_batch_and_log_callback(ctx, oracle):
+    pairs = []
+    for s in range(3):
+        p = synth.frustum_pair(1500 + 100 * s, seed=20 + s, rot_deg=(0, 1, 0), shift=(0.01, 0, 0))
+        pairs.append((p["source"], p["target"]))
+    log = []
+    ctx.set_log_callback(lambda k, q, us: log.append((k, q, us)))
+    T, st, rc = ctx.align_batch(pairs, solve=binding.SOLVE_KABSCH, max_iterations=5, fixed_iterations=1)
+    ctx.set_log_callback(None)
+    assert rc == 0 and T.shape == (3, 4, 4)
+    for b, (s, t) in enumerate(pairs):
+        o = oracle.align(s, t, max_iterations=5, solve=1, sum_order=1, fixed_iterations=True, threads=4)
+        assert np.array_equal(T[b], o["T"]) and st[b].iterations == 5
+    keys = [k for k, _, _ in log]
+    assert keys.count(0) == 3 * 6 and keys.count(6) == 3 * 5  # LOG_NEAREST_NEIGHBOR, LOG_SVD (SLAM.hpp:4,10)
+    assert all(us >= 0 for _, _, us in log)
+
+
+def test_profile_stats(ctx):
+    p = synth.frustum_pair(4000, seed=9)
+    ctx.set_target(p["target"])
+    ctx.set_source(p["source"])
+    T, st, rc = ctx.align(max_iterations=3, fixed_iterations=1, profile=1, solve=binding.SOLVE_KABSCH)
+    assert st.nn_launches == 4 and st.nn_ms_total > 0 and st.reduce_ms_total > 0 and st.transform_ms_total > 0
+    assert st.total_ms >= st.nn_ms_total
+
+
+# -------------------------------------------------------------- backproject --
+def test_backproject_bit_exact(ctx, oracle):
+    rng = np.random.default_rng(10)
+    for rows, cols, frac in [(48, 64, 0.5), (480, 640, 0.3), (33, 47, 0.9), (8, 8, 0.0)]:
+        depth = rng.integers(1, 20000, (rows, cols)).astype(np.uint16)
+        depth[rng.random(depth.shape) >= frac] = 0
+        want = oracle.backproject(depth)
+        n = ctx.backproject(depth, which=0)
+        assert n == want.shape[1]
+        got = ctx.get_source()
+        assert np.array_equal(got, want)
+        off = np.array([5, 5, 5], np.float32)
+        n = ctx.backproject(depth, which=0, offset=off)
+        assert np.array_equal(ctx.get_source(), want + off[:, None])
+    # both clouds from depth images, then NN: same result as uploading the clouds
+    p = synth.kinect_pair(rows=120, cols=160, seed=4)
+    ctx.backproject(p["depth_tgt"], which=1, offset=[5, 5, 5])
+    ctx.backproject(p["depth_src"], which=0, offset=[5, 5, 5])
+    assert np.array_equal(ctx.get_source(), p["source"])
+    idx, dist = ctx.nn()
+    oidx, odist = oracle.nn_bruteforce(p["source"], p["target"], threads=4)
+    assert np.array_equal(idx, oidx) and np.array_equal(dist, odist)
