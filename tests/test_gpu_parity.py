@@ -91,14 +91,24 @@ def test_nn_sqrt_collision_classes(ctx, oracle):
     tgt = np.stack([xs, np.zeros_like(xs), np.zeros_like(xs)])
     src = np.zeros((3, 1), np.float32)
     _check_nn(ctx, oracle, src, tgt)
-    # squared distances 1 ulp apart mapping to the same sqrt: use y so that xyz varies finely
+    # squared distances exactly 1 ulp apart (x = 1, y^2 = k * 2^-23) that map to the same
+    # float sqrt: the class of the minimum holds k = 1 (index 62) and k = 0 (index 63);
+    # the reference keeps index 62 although its squared distance is the larger one
     q = np.zeros((3, 1), np.float32)
-    ys = np.sqrt(np.float32(2.0) + np.arange(64, dtype=np.float32) * np.float32(2.4e-7))[::-1].copy()
-    tgt = np.stack([np.zeros_like(ys), ys, np.zeros_like(ys)]).astype(np.float32)
+    k = np.arange(63, -1, -1).astype(np.float64)
+    ys = np.sqrt(k * 2.0 ** -23).astype(np.float32)
+    tgt = np.stack([np.ones_like(ys), ys, np.zeros_like(ys)]).astype(np.float32)
+    xyz = (tgt[0].astype(np.float64) ** 2 + tgt[1].astype(np.float64) ** 2).astype(np.float32)
+    assert xyz[62] > xyz[63]
     idx, dist = _check_nn(ctx, oracle, q, tgt)
     d_all = np.array([oracle.distance(q[:, 0], tgt[:, j]) for j in range(tgt.shape[1])])
-    assert (d_all == d_all.min()).sum() >= 2  # the collision really occurs
-    assert idx[0] == np.flatnonzero(d_all == d_all.min())[0]
+    assert list(np.flatnonzero(d_all == d_all.min())) == [62, 63]  # the collision really occurs
+    assert idx[0] == 62 and dist[0] == np.float32(1.0)
+    # same thing with the two class members in different LDS tiles / target chunks
+    far = np.full((3, 3000), 50, np.float32)
+    tgt2 = np.concatenate([tgt[:, :63], far, tgt[:, 63:]], axis=1)
+    idx, dist = _check_nn(ctx, oracle, q, tgt2)
+    assert idx[0] == 62
 
 
 def test_nn_config1_10k(ctx, oracle):
