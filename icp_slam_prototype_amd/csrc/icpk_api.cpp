@@ -39,7 +39,10 @@ struct icpk_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   Cloud tgt, src0, src;
+  Cloud dec;  // every NN_SEED_STRIDE-th target (seeding pre-pass of the filtered NN)
   bool have_tgt = false, have_src = false, have_assoc = false;
+  bool have_dec = false;   // dec matches tgt
+  bool have_seed = false;  // `best` holds matches of a previous sweep of the same clouds
   nn_key_t* best = nullptr;
   nn_key_t* seed = nullptr;
   int32_t* idx = nullptr;
@@ -56,6 +59,7 @@ struct icpk_ctx {
   int* bp_n_host = nullptr;  // pinned
   std::vector<hipEvent_t> events;
   int target_blocks = 16384;
+  int q_per_lane = 0;  // 0 = auto
   std::string err;
   icpk_log_fn log_fn = nullptr;
   void* log_user = nullptr;
@@ -84,7 +88,8 @@ int ensure_cloud(icpk_ctx* ctx, Cloud& c, int n) {
     if (c.base) ICPK_HIP(ctx, hipFree(c.base));
     c.base = nullptr;
     c.cap = 0;
-    ICPK_HIP(ctx, hipMalloc((void**)&c.base, (size_t)3 * cap * sizeof(float)));
+    // +64 floats: the filtered NN kernel prefetches one group past its chunk
+    ICPK_HIP(ctx, hipMalloc((void**)&c.base, ((size_t)3 * cap + 64) * sizeof(float)));
     c.cap = cap;
   }
   c.n = n;
@@ -102,6 +107,7 @@ int ensure_assoc(icpk_ctx* ctx, int nq) {
     ctx->idx = nullptr;
     ctx->dist = nullptr;
     ctx->assoc_cap = 0;
+    ctx->have_seed = false;
     ICPK_HIP(ctx, hipMalloc((void**)&ctx->best, (size_t)cap * sizeof(nn_key_t)));
     ICPK_HIP(ctx, hipMalloc((void**)&ctx->seed, (size_t)cap * sizeof(nn_key_t)));
     ICPK_HIP(ctx, hipMalloc((void**)&ctx->idx, (size_t)cap * sizeof(int32_t)));
@@ -173,7 +179,7 @@ int check_ready(icpk_ctx* ctx) {
 
 // enqueue one NN sweep (K1) over the working source
 int enqueue_nn(icpk_ctx* ctx, int nn_mode) {
-  if (nn_mode != ICPK_NN_EXACT) return fail(ctx, ICPK_E_ARG, "unknown nn_mode");
+  if (nn_mode != ICPK_NN_EXACT && nn_mode != ICPK_NN_FILTERED) return fail(ctx, ICPK_E_ARG, "unknown nn_mode");
   const int nq = ctx->src.n;
   int rc = ensure_assoc(ctx, nq);
   if (rc) return rc;
@@ -181,6 +187,12 @@ int enqueue_nn(icpk_ctx* ctx, int nn_mode) {
     ctx->have_assoc = true;
     return ICPK_OK;
   }
+  auto chunking = [&](int nqb, int ntiles) {
+    int nchunks = (ctx->target_blocks + nqb - 1) / nqb;
+    if (nchunks < 1) nchunks = 1;
+    if (nchunks > ntiles) nchunks = ntiles;
+    return (ntiles + nchunks - 1) / nchunks;
+  };
   NnArgs a;
   a.qx = ctx->src.x();
   a.qy = ctx->src.y();
@@ -191,16 +203,48 @@ int enqueue_nn(icpk_ctx* ctx, int nn_mode) {
   a.tz = ctx->tgt.z();
   a.nt_pad = round_up(ctx->tgt.n, NN_TILE);
   const int ntiles = a.nt_pad / NN_TILE;
-  const int nqb = (nq + NN_THREADS - 1) / NN_THREADS;
-  int nchunks = (ctx->target_blocks + nqb - 1) / nqb;
-  if (nchunks < 1) nchunks = 1;
-  if (nchunks > ntiles) nchunks = ntiles;
-  a.tiles_per_chunk = (ntiles + nchunks - 1) / nchunks;
-  a.best = ctx->best;
-  launch_fill_u64(ctx->best, nq, NN_KEY_INIT, ctx->stream);
-  launch_nn_exact(a, ctx->stream);
+  if (nn_mode == ICPK_NN_EXACT) {
+    a.tiles_per_chunk = chunking((nq + NN_THREADS - 1) / NN_THREADS, ntiles);
+    a.best = ctx->best;
+    launch_fill_u64(ctx->best, nq, NN_KEY_INIT, ctx->stream);
+    launch_nn_exact(a, ctx->stream);
+  } else {
+    int seed_scale = 1;
+    if (ctx->have_seed) {
+      // matches of the previous sweep (same clouds, source possibly moved) seed this one
+      nn_key_t* t = ctx->seed;
+      ctx->seed = ctx->best;
+      ctx->best = t;
+    } else {
+      // coarse pre-pass: exact NN against every NN_SEED_STRIDE-th target
+      if (!ctx->have_dec) {
+        const int nd = (ctx->tgt.n + NN_SEED_STRIDE - 1) / NN_SEED_STRIDE;
+        rc = ensure_cloud(ctx, ctx->dec, nd);
+        if (rc) return rc;
+        launch_decimate(ctx->tgt.x(), ctx->tgt.y(), ctx->tgt.z(), ctx->tgt.n, NN_SEED_STRIDE, ctx->dec.x(),
+                        ctx->dec.y(), ctx->dec.z(), round_up(nd, NN_TILE), ctx->stream);
+        ctx->have_dec = true;
+      }
+      NnArgs c = a;
+      c.tx = ctx->dec.x();
+      c.ty = ctx->dec.y();
+      c.tz = ctx->dec.z();
+      c.nt_pad = round_up(ctx->dec.n, NN_TILE);
+      c.tiles_per_chunk = chunking((nq + NN_THREADS - 1) / NN_THREADS, c.nt_pad / NN_TILE);
+      c.best = ctx->seed;
+      launch_fill_u64(ctx->seed, nq, NN_KEY_INIT, ctx->stream);
+      launch_nn_exact(c, ctx->stream);
+      seed_scale = NN_SEED_STRIDE;
+    }
+    const int q = ctx->q_per_lane > 0 ? ctx->q_per_lane : (nq >= 65536 ? 2 : 1);
+    a.tiles_per_chunk = chunking((nq + NN_THREADS * q - 1) / (NN_THREADS * q), ntiles);
+    a.best = ctx->best;
+    launch_fill_u64(ctx->best, nq, NN_KEY_INIT, ctx->stream);
+    launch_nn_filtered(a, ctx->seed, seed_scale, q, ctx->stream);
+  }
   ICPK_HIP(ctx, hipGetLastError());
   ctx->have_assoc = true;
+  ctx->have_seed = true;
   return ICPK_OK;
 }
 
@@ -263,6 +307,10 @@ int icpk_create(icpk_ctx** out, int device_id) {
     const int v = std::atoi(e);
     if (v > 0) ctx->target_blocks = v;
   }
+  if (const char* e = std::getenv("ICPK_NN_Q")) {
+    const int v = std::atoi(e);
+    if (v == 1 || v == 2) ctx->q_per_lane = v;
+  }
   ctx->log_last = std::chrono::steady_clock::now();
   *out = ctx;
   return ICPK_OK;
@@ -273,7 +321,7 @@ void icpk_destroy(icpk_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   for (hipEvent_t e : ctx->events) (void)hipEventDestroy(e);
-  void* dev[] = {ctx->tgt.base, ctx->src0.base, ctx->src.base, ctx->best,      ctx->seed,     ctx->idx,
+  void* dev[] = {ctx->dec.base, ctx->tgt.base, ctx->src0.base, ctx->src.base, ctx->best,      ctx->seed,     ctx->idx,
                  ctx->dist,     ctx->partial,   ctx->pcount,   ctx->red_out,   ctx->depth_dev, ctx->bp_counts};
   for (void* p : dev)
     if (p) (void)hipFree(p);
@@ -302,6 +350,8 @@ static int set_target_impl(icpk_ctx* ctx, const float* x, const float* y, const 
   if (rc) return rc;
   ctx->have_tgt = true;
   ctx->have_assoc = false;
+  ctx->have_dec = false;
+  ctx->have_seed = false;
   return ICPK_OK;
 }
 
@@ -312,6 +362,7 @@ static int set_source_impl(icpk_ctx* ctx, const float* x, const float* y, const 
   if (rc) return rc;
   ctx->have_src = true;
   ctx->have_assoc = false;
+  ctx->have_seed = false;
   rc = copy_src0_to_src(ctx);
   if (rc) return rc;
   ICPK_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -338,6 +389,7 @@ int icpk_reset_source(icpk_ctx* ctx) {
   int rc = copy_src0_to_src(ctx);
   if (rc) return rc;
   ctx->have_assoc = false;
+  ctx->have_seed = false;
   ICPK_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return ICPK_OK;
 }
@@ -434,6 +486,7 @@ int icpk_align(icpk_ctx* ctx, const icpk_params* p, float T_out[16], icpk_stats*
   ICPK_HIP(ctx, hipSetDevice(ctx->device));
   rc = copy_src0_to_src(ctx);
   if (rc) return rc;
+  ctx->have_seed = false;  // matches of an earlier alignment belong to a different source pose
 
   const bool prof = p->profile != 0;
   size_t nev = 0;
@@ -649,6 +702,8 @@ int icpk_backproject(icpk_ctx* ctx, const uint16_t* depth, int32_t rows, int32_t
   launch_fill_f32(c.z() + n, padded - n, pad, ctx->stream);
   ICPK_HIP(ctx, hipGetLastError());
   ctx->have_assoc = false;
+  ctx->have_seed = false;
+  if (which == 1) ctx->have_dec = false;
   if (which == 0) {
     ctx->have_src = true;
     rc = copy_src0_to_src(ctx);

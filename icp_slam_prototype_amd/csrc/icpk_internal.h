@@ -52,7 +52,10 @@ inline int red_blocks(int n) {
 // kernels_nn.hip
 void launch_fill_u64(nn_key_t* p, int n, nn_key_t v, hipStream_t s);
 void launch_nn_exact(const NnArgs& a, hipStream_t s);
-void launch_nn_filtered(const NnArgs& a, const nn_key_t* seed, hipStream_t s);
+void launch_nn_filtered(const NnArgs& a, const nn_key_t* seed, int seed_scale, int q_per_lane, hipStream_t s);
+void launch_decimate(const float* x, const float* y, const float* z, int n, int stride, float* ox, float* oy, float* oz,
+                     int n_out_pad, hipStream_t s);
+constexpr int NN_SEED_STRIDE = 16;  // decimation of the target for the seeding pre-pass
 void launch_pair_distance(const float* a, const float* b, float* out, int n, hipStream_t s);
 
 // kernels_reduce.hip

@@ -131,6 +131,182 @@ void launch_nn_exact(const NnArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(nn_exact_kernel, grid, dim3(NN_THREADS), 0, s, a);
 }
 
+// ---- K1 filtered ------------------------------------------------------------------
+// Same result as nn_exact_kernel, ~7 fp32 VALU per pair instead of ~32 mixed
+// fp64/fp32: every query starts from a SEED candidate (its match of the previous
+// ICP iteration, or of a coarse pre-pass over a decimated target) whose exact
+// distance d_b bounds the search.  A target can only change the answer if its
+// float distance is <= d_b, which implies ("filter bound")
+//     e = fmaf(dz,dz, fmaf(dy,dy, dx*dx))  <=  T(d_b) = d_b^2 (1 + 2^-20) + 2^-120
+// so the inner loop evaluates only e (fp32) and compares it with the per-lane
+// threshold; the rare groups in which some lane passes are re-evaluated with the
+// exact pair_dist() and merged lexicographically on (distance, index), which is
+// order independent and equals the reference scan's "strict <, lowest index".
+//
+// Targets are wave-uniform, so they are fetched with scalar loads (s_load_dwordx8
+// through the scalar cache) and consumed as SGPR operands: no LDS staging, no
+// barriers, no VGPRs for target data.
+constexpr int NNF_G = 8;  // targets per group: one s_load_dwordx8 per plane
+
+__device__ __forceinline__ float filt_threshold(float d) {
+  const float t = __builtin_fmaf(d * d, 1.0f + 0x1p-20f, 0x1p-120f);
+  return (t == t) ? t : __builtin_inff();  // NaN best (garbage input): pass everything
+}
+
+// fast path for one group of NNF_G wave-uniform targets: returns, per query of this
+// lane, the smallest fp32 estimate e over the group (v_min3_f32 folds two per op)
+template <int Q>
+__device__ __forceinline__ void group_min(const float (&qx)[Q], const float (&qy)[Q], const float (&qz)[Q],
+                                          const float (&X)[NNF_G], const float (&Y)[NNF_G], const float (&Z)[NNF_G],
+                                          float (&m)[Q]) {
+#pragma unroll
+  for (int u = 0; u < Q; ++u) m[u] = __builtin_inff();
+#pragma unroll
+  for (int k = 0; k < NNF_G; k += 2) {
+#pragma unroll
+    for (int u = 0; u < Q; ++u) {
+      const float dx0 = qx[u] - X[k], dy0 = qy[u] - Y[k], dz0 = qz[u] - Z[k];
+      const float dx1 = qx[u] - X[k + 1], dy1 = qy[u] - Y[k + 1], dz1 = qz[u] - Z[k + 1];
+      const float e0 = __builtin_fmaf(dz0, dz0, __builtin_fmaf(dy0, dy0, dx0 * dx0));
+      const float e1 = __builtin_fmaf(dz1, dz1, __builtin_fmaf(dy1, dy1, dx1 * dx1));
+      m[u] = __builtin_fminf(m[u], __builtin_fminf(e0, e1));
+    }
+  }
+}
+
+// slow path: exact re-evaluation of the whole group, lexicographic (d, j) merge
+template <int Q>
+__device__ __forceinline__ void group_exact(const float (&qx)[Q], const float (&qy)[Q], const float (&qz)[Q],
+                                            const float (&X)[NNF_G], const float (&Y)[NNF_G], const float (&Z)[NNF_G],
+                                            int j, float (&bd)[Q], int (&bj)[Q], float (&T)[Q]) {
+#pragma unroll
+  for (int k = 0; k < NNF_G; ++k) {
+#pragma unroll
+    for (int u = 0; u < Q; ++u) {
+      const float d = pair_dist(qx[u], qy[u], qz[u], X[k], Y[k], Z[k]);
+      const int jj = j + k;
+      const bool up = (d < bd[u]) | ((d == bd[u]) & (jj < bj[u]));
+      bd[u] = up ? d : bd[u];
+      bj[u] = up ? jj : bj[u];
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < Q; ++u) T[u] = filt_threshold(bd[u]);
+}
+
+template <int Q>
+__global__ __launch_bounds__(NN_THREADS) void nn_filtered_kernel(
+    const float* __restrict__ qxp, const float* __restrict__ qyp, const float* __restrict__ qzp, int nq,
+    const float* __restrict__ txp, const float* __restrict__ typ, const float* __restrict__ tzp, int nt_pad,
+    int tiles_per_chunk, const nn_key_t* __restrict__ seed, int seed_scale, nn_key_t* __restrict__ best) {
+  const int tid = threadIdx.x;
+  const int ibase = blockIdx.x * (NN_THREADS * Q) + tid;
+  float qx[Q], qy[Q], qz[Q], bd[Q], T[Q];
+  int bj[Q];
+  nn_key_t key0[Q];
+#pragma unroll
+  for (int u = 0; u < Q; ++u) {
+    const int i = ibase + u * NN_THREADS;
+    const bool live = i < nq;
+    qx[u] = live ? qxp[i] : 0.f;
+    qy[u] = live ? qyp[i] : 0.f;
+    qz[u] = live ? qzp[i] : 0.f;
+    int js = live ? (int)(unsigned)(seed[i] & 0xffffffffu) * seed_scale : 0;
+    float ds = pair_dist(qx[u], qy[u], qz[u], txp[js], typ[js], tzp[js]);
+    if (!(ds <= 3.402823466e38f)) {  // inf/NaN: fall back to the reference's literal seed, element 0
+      js = 0;
+      ds = pair_dist(qx[u], qy[u], qz[u], txp[0], typ[0], tzp[0]);
+    }
+    bd[u] = ds;
+    bj[u] = js;
+    T[u] = filt_threshold(ds);
+    key0[u] = ((nn_key_t)__float_as_uint(ds) << 32) | (nn_key_t)(unsigned)js;
+  }
+
+  const int j0 = blockIdx.y * tiles_per_chunk * NN_TILE;
+  int j1 = j0 + tiles_per_chunk * NN_TILE;
+  if (j1 > nt_pad) j1 = nt_pad;
+
+  // two SGPR buffers (A, B) of NNF_G targets: the scalar loads of one group are in
+  // flight while the other is consumed.  The last prefetch reads NNF_G floats past
+  // the chunk; every cloud allocation carries that much slack.
+  float XA[NNF_G], YA[NNF_G], ZA[NNF_G], XB[NNF_G], YB[NNF_G], ZB[NNF_G];
+#pragma unroll
+  for (int k = 0; k < NNF_G; ++k) {
+    XA[k] = txp[j0 + k];
+    YA[k] = typ[j0 + k];
+    ZA[k] = tzp[j0 + k];
+  }
+  for (int j = j0; j < j1; j += 2 * NNF_G) {
+#pragma unroll
+    for (int k = 0; k < NNF_G; ++k) {
+      XB[k] = txp[j + NNF_G + k];
+      YB[k] = typ[j + NNF_G + k];
+      ZB[k] = tzp[j + NNF_G + k];
+    }
+    float m[Q];
+    bool hit;
+    group_min<Q>(qx, qy, qz, XA, YA, ZA, m);
+    hit = false;
+#pragma unroll
+    for (int u = 0; u < Q; ++u) hit |= (m[u] <= T[u]);
+    if (__builtin_amdgcn_ballot_w64(hit) != 0) group_exact<Q>(qx, qy, qz, XA, YA, ZA, j, bd, bj, T);
+#pragma unroll
+    for (int k = 0; k < NNF_G; ++k) {
+      XA[k] = txp[j + 2 * NNF_G + k];
+      YA[k] = typ[j + 2 * NNF_G + k];
+      ZA[k] = tzp[j + 2 * NNF_G + k];
+    }
+    group_min<Q>(qx, qy, qz, XB, YB, ZB, m);
+    hit = false;
+#pragma unroll
+    for (int u = 0; u < Q; ++u) hit |= (m[u] <= T[u]);
+    if (__builtin_amdgcn_ballot_w64(hit) != 0) group_exact<Q>(qx, qy, qz, XB, YB, ZB, j + NNF_G, bd, bj, T);
+  }
+
+#pragma unroll
+  for (int u = 0; u < Q; ++u) {
+    const int i = ibase + u * NN_THREADS;
+    const nn_key_t key = ((nn_key_t)__float_as_uint(bd[u]) << 32) | (nn_key_t)(unsigned)bj[u];
+    // chunk 0 always publishes (so the seed candidate itself is in the result);
+    // the others only if they improved on it
+    if (i < nq && (blockIdx.y == 0 || key < key0[u])) atomicMin(&best[i], key);
+  }
+}
+
+void launch_nn_filtered(const NnArgs& a, const nn_key_t* seed, int seed_scale, int q_per_lane, hipStream_t s) {
+  const int ntiles = a.nt_pad / NN_TILE;
+  const int nchunks = (ntiles + a.tiles_per_chunk - 1) / a.tiles_per_chunk;
+  if (q_per_lane == 2) {
+    dim3 grid((a.nq + 2 * NN_THREADS - 1) / (2 * NN_THREADS), nchunks);
+    hipLaunchKernelGGL(nn_filtered_kernel<2>, grid, dim3(NN_THREADS), 0, s, a.qx, a.qy, a.qz, a.nq, a.tx, a.ty, a.tz,
+                       a.nt_pad, a.tiles_per_chunk, seed, seed_scale, a.best);
+  } else {
+    dim3 grid((a.nq + NN_THREADS - 1) / NN_THREADS, nchunks);
+    hipLaunchKernelGGL(nn_filtered_kernel<1>, grid, dim3(NN_THREADS), 0, s, a.qx, a.qy, a.qz, a.nq, a.tx, a.ty, a.tz,
+                       a.nt_pad, a.tiles_per_chunk, seed, seed_scale, a.best);
+  }
+}
+
+// every `stride`-th target -> coarse cloud for the seeding pre-pass
+__global__ void decimate_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z,
+                                int n, int stride, float* __restrict__ ox, float* __restrict__ oy,
+                                float* __restrict__ oz, int n_out_pad) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n_out_pad) return;
+  const long long j = (long long)k * stride;
+  const bool ok = j < n;
+  ox[k] = ok ? x[j] : __builtin_inff();
+  oy[k] = ok ? y[j] : __builtin_inff();
+  oz[k] = ok ? z[j] : __builtin_inff();
+}
+
+void launch_decimate(const float* x, const float* y, const float* z, int n, int stride, float* ox, float* oy, float* oz,
+                     int n_out_pad, hipStream_t s) {
+  hipLaunchKernelGGL(decimate_kernel, dim3((n_out_pad + 255) / 256), dim3(256), 0, s, x, y, z, n, stride, ox, oy, oz,
+                     n_out_pad);
+}
+
 // ---- test hook: the pair distance on its own --------------------------------
 __global__ void pair_distance_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
                                      int n) {

@@ -71,17 +71,25 @@ __global__ __launch_bounds__(RED_THREADS) void assoc_reduce_kernel(
   if (tid == NSUM) pcount[blockIdx.x] = wc[0] + wc[1] + wc[2] + wc[3];
 }
 
-// blocks are added in block order by one lane per quantity
-__global__ void reduce_final_kernel(const double* __restrict__ partial, const int* __restrict__ pcount, int nblocks,
-                                    double* __restrict__ out) {
+// blocks are added in block order by one lane per quantity; the partials are
+// first staged in LDS with coalesced loads so the serial adds do not each wait
+// on a global-memory round trip
+__global__ __launch_bounds__(256) void reduce_final_kernel(const double* __restrict__ partial,
+                                                           const int* __restrict__ pcount, int nblocks,
+                                                           double* __restrict__ out) {
+  __shared__ double sp[RED_MAX_BLOCKS * NSUM];
+  __shared__ int sc[RED_MAX_BLOCKS];
   const int tid = threadIdx.x;
+  for (int k = tid; k < nblocks * NSUM; k += 256) sp[k] = partial[k];
+  for (int k = tid; k < nblocks; k += 256) sc[k] = pcount[k];
+  __syncthreads();
   if (tid < NSUM) {
     double t = 0.0;
-    for (int b = 0; b < nblocks; ++b) t += partial[b * NSUM + tid];
+    for (int b = 0; b < nblocks; ++b) t += sp[b * NSUM + tid];
     out[tid] = t;
   } else if (tid == NSUM) {
     long long c = 0;
-    for (int b = 0; b < nblocks; ++b) c += pcount[b];
+    for (int b = 0; b < nblocks; ++b) c += sc[b];
     reinterpret_cast<long long*>(out)[NSUM] = c;
   }
 }
@@ -92,7 +100,7 @@ void launch_assoc_reduce(const nn_key_t* best, const float* ax, const float* ay,
   const int B = red_blocks(nq);
   hipLaunchKernelGGL(assoc_reduce_kernel, dim3(B), dim3(RED_THREADS), 0, s, best, ax, ay, az, nq, tx, ty, tz,
                      max_dist, idx_out, dist_out, partial, pcount);
-  hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(64), 0, s, partial, pcount, B, out);
+  hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(256), 0, s, partial, pcount, B, out);
 }
 
 }  // namespace icpk

@@ -312,3 +312,121 @@ def test_backproject_bit_exact(ctx, oracle):
     idx, dist = ctx.nn()
     oidx, odist = oracle.nn_bruteforce(p["source"], p["target"], threads=4)
     assert np.array_equal(idx, oidx) and np.array_equal(dist, odist)
+
+
+# ------------------------------------------------- filtered NN (ICPK_NN_FILTERED) --
+def _check_nn_filtered(ctx, oracle, src, tgt, moves=2):
+    """First sweep (coarse-seeded) and re-sweeps after moving the source (seeded by
+    the previous matches) must equal the oracle bit for bit."""
+    ctx.set_target(tgt)
+    ctx.set_source(src)
+    cur = src
+    for it in range(moves + 1):
+        idx, dist = ctx.nn(binding.NN_FILTERED)
+        oidx, odist = oracle.nn_bruteforce(cur, tgt, threads=oracle.max_threads())
+        assert np.array_equal(idx, oidx), f"sweep {it}"
+        assert np.array_equal(dist.view(np.uint32), odist.view(np.uint32)), f"sweep {it}"
+        R = oracle.make_rotation_matrix(0.3 * (it + 1), -0.2, 0.1)
+        t = np.array([0.004, -0.003, 0.002], np.float32) * (it + 1)
+        ctx.transform_source(R, t)
+        cur = oracle.transform_points(cur, R, t)
+
+
+@pytest.mark.parametrize("nq,nt", [(1, 1), (1, 5), (5, 1), (63, 65), (256, 1024), (257, 1025), (1000, 3000),
+                                   (3000, 1000), (4096, 4096), (700, 17), (20000, 9000)])
+def test_nn_filtered_random_sizes(ctx, oracle, nq, nt):
+    rng = np.random.default_rng(nq * 104729 + nt)
+    src = (rng.uniform(-2, 2, (3, nq)) + 5).astype(np.float32)
+    tgt = (rng.uniform(-2, 2, (3, nt)) + 5).astype(np.float32)
+    _check_nn_filtered(ctx, oracle, src, tgt)
+
+
+def test_nn_filtered_ties_collisions_duplicates(ctx, oracle):
+    p = synth.lattice_wall(60, 80)
+    _check_nn_filtered(ctx, oracle, p["source"], p["target"])
+    tgt2 = np.concatenate([p["target"], p["target"]], axis=1)  # exact twins 4800 later
+    _check_nn_filtered(ctx, oracle, p["source"], tgt2)
+    ctx.set_target(tgt2)
+    ctx.set_source(p["source"])
+    idx, _ = ctx.nn(binding.NN_FILTERED)
+    assert (idx < 4800).all()
+    # sqrt-collision class: indices 62 and 63 share the float distance, 62 must win
+    q = np.zeros((3, 1), np.float32)
+    k = np.arange(63, -1, -1).astype(np.float64)
+    ys = np.sqrt(k * 2.0 ** -23).astype(np.float32)
+    tgt = np.stack([np.ones_like(ys), ys, np.zeros_like(ys)]).astype(np.float32)
+    far = np.full((3, 3000), 50, np.float32)
+    for t in (tgt, np.concatenate([tgt[:, :63], far, tgt[:, 63:]], axis=1)):
+        ctx.set_target(t)
+        ctx.set_source(q)
+        idx, dist = ctx.nn(binding.NN_FILTERED)
+        assert idx[0] == 62 and dist[0] == np.float32(1.0)
+    # query identical to a target (distance 0, threshold 0 + slack) and all-equal targets
+    tgt = np.tile(np.array([[1.0], [2.0], [3.0]], np.float32), (1, 2000))
+    src = np.array([[1.0, 1.5], [2.0, 2.0], [3.0, 3.0]], np.float32)
+    _check_nn_filtered(ctx, oracle, src, tgt, moves=0)
+    ctx.set_target(tgt)
+    ctx.set_source(src)
+    idx, dist = ctx.nn(binding.NN_FILTERED)
+    assert list(idx) == [0, 0] and dist[0] == 0
+
+
+def test_nn_filtered_far_apart_and_tiny_scale(ctx, oracle):
+    rng = np.random.default_rng(3)
+    tgt = (rng.uniform(-2, 2, (3, 5000)) + 5).astype(np.float32)
+    src = (rng.uniform(-2, 2, (3, 3000)) + 500).astype(np.float32)  # seeds are ~850 m away
+    _check_nn_filtered(ctx, oracle, src, tgt, moves=1)
+    tgt = (rng.uniform(-1, 1, (3, 4000)) * 1e-12).astype(np.float32)  # squares near the denormal range
+    src = (rng.uniform(-1, 1, (3, 2000)) * 1e-12).astype(np.float32)
+    _check_nn_filtered(ctx, oracle, src, tgt, moves=0)
+    tgt = (rng.uniform(-1, 1, (3, 4000)) * 1e-21).astype(np.float32)  # squares underflow to 0 in fp32
+    src = (rng.uniform(-1, 1, (3, 500)) * 1e-21).astype(np.float32)
+    _check_nn_filtered(ctx, oracle, src, tgt, moves=0)
+
+
+def test_nn_filtered_kinect_quarter_frame_and_exact_agree(ctx, oracle):
+    p = synth.kinect_pair(rows=240, cols=320, seed=2)
+    _check_nn_filtered(ctx, oracle, p["source"], p["target"], moves=2)
+    ctx.set_target(p["target"])
+    ctx.set_source(p["source"])
+    a = ctx.nn(binding.NN_EXACT)
+    b = ctx.nn(binding.NN_FILTERED)  # seeded by the exact sweep's matches
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+@pytest.mark.parametrize("solve", [binding.SOLVE_REFERENCE, binding.SOLVE_KABSCH])
+def test_align_filtered_matches_oracle(ctx, oracle, solve):
+    p = synth.kinect_pair(rows=240, cols=320, seed=3)
+    T, st, rc, o = _align_both(ctx, oracle, p["source"], p["target"], solve=solve, max_iterations=6,
+                               fixed_iterations=1, nn_mode=binding.NN_FILTERED)
+    assert st.iterations == o["iterations"] == 6
+    assert np.array_equal(T, o["T"])  # bit-identical, not just within 1e-5
+    idx, dist = ctx.get_associations()
+    assert np.array_equal(idx, o["idx"]) and np.array_equal(dist.view(np.uint32), o["dist"].view(np.uint32))
+    assert np.array_equal(ctx.get_source().view(np.uint32), o["src_out"].view(np.uint32))
+    T2, st2, _ = ctx.align(solve=solve, max_iterations=6, fixed_iterations=1, nn_mode=binding.NN_EXACT)
+    assert np.array_equal(T, T2)
+
+
+def test_full_size_kinect_pair_properties(ctx):
+    """BASELINE config 2 at full size (~92k x 92k): too big for the oracle in
+    seconds, so check size-independent properties: exact and filtered kernels
+    agree bit for bit, every distance equals the pair distance to the reported
+    index, and no target is closer than the reported one on a random subset."""
+    p = synth.kinect_pair(480, 640, valid=0.30, seed=2)
+    src, tgt = p["source"], p["target"]
+    assert 88000 < src.shape[1] < 96000
+    ctx.set_target(tgt)
+    ctx.set_source(src)
+    ie, de = ctx.nn(binding.NN_EXACT)
+    ctx.reset_source()  # drops the seeds: the filtered sweep starts from the coarse pre-pass
+    i_f, d_f = ctx.nn(binding.NN_FILTERED)
+    assert np.array_equal(ie, i_f) and np.array_equal(de.view(np.uint32), d_f.view(np.uint32))
+    assert np.array_equal(ctx.pair_distance(src, tgt[:, ie]).view(np.uint32), de.view(np.uint32))
+    rng = np.random.default_rng(0)
+    for q in rng.integers(0, src.shape[1], 40):
+        d = ctx.pair_distance(np.repeat(src[:, q:q + 1], tgt.shape[1], axis=1), tgt)
+        assert d.min() == de[q] and np.flatnonzero(d == d.min())[0] == ie[q]
+    T1, st1, _ = ctx.align(max_iterations=3, fixed_iterations=1, nn_mode=binding.NN_EXACT)
+    T2, st2, _ = ctx.align(max_iterations=3, fixed_iterations=1, nn_mode=binding.NN_FILTERED)
+    assert np.array_equal(T1, T2) and st1.final_pairs == st2.final_pairs and st1.final_mse == st2.final_mse
