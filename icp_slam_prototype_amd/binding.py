@@ -23,8 +23,9 @@ NSUM = 19
 SYMBOLS = [
     "icpk_version", "icpk_create", "icpk_destroy", "icpk_last_error", "icpk_default_params",
     "icpk_set_log_callback", "icpk_stream", "icpk_set_target", "icpk_set_source", "icpk_set_target_device",
-    "icpk_set_source_device", "icpk_reset_source", "icpk_get_source", "icpk_source_size", "icpk_target_size",
-    "icpk_nn", "icpk_reduce", "icpk_transform_source", "icpk_get_associations", "icpk_align",
+    "icpk_set_source_device", "icpk_reset_source", "icpk_commit_source", "icpk_get_source", "icpk_get_target", "icpk_source_size", "icpk_target_size",
+    "icpk_nn", "icpk_reduce", "icpk_transform_source", "icpk_transform_target", "icpk_get_trace",
+    "icpk_get_associations", "icpk_align",
     "icpk_align_batch", "icpk_backproject", "icpk_pair_distance", "icpk_make_rotation_matrix",
     "icpk_matrix_to_quaternion", "icpk_quaternion_to_euler", "icpk_solve_reference", "icpk_solve_kabsch",
 ]
@@ -103,12 +104,16 @@ def load():
     for name in ("icpk_set_target_device", "icpk_set_source_device"):
         getattr(lib, name).argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
     lib.icpk_reset_source.argtypes = [C.c_void_p]
+    lib.icpk_commit_source.argtypes = [C.c_void_p]
     lib.icpk_get_source.argtypes = [C.c_void_p, fp, fp, fp]
+    lib.icpk_get_target.argtypes = [C.c_void_p, fp, fp, fp]
     lib.icpk_source_size.argtypes = [C.c_void_p]
     lib.icpk_target_size.argtypes = [C.c_void_p]
     lib.icpk_nn.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), fp]
     lib.icpk_reduce.argtypes = [C.c_void_p, C.c_float, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     lib.icpk_transform_source.argtypes = [C.c_void_p, fp, fp]
+    lib.icpk_transform_target.argtypes = [C.c_void_p, fp, fp]
+    lib.icpk_get_trace.argtypes = [C.c_void_p, C.POINTER(C.c_int32), fp, fp, C.POINTER(C.c_int32), fp]
     lib.icpk_get_associations.argtypes = [C.c_void_p, C.POINTER(C.c_int32), fp]
     lib.icpk_align.argtypes = [C.c_void_p, C.POINTER(Params), fp, C.POINTER(Stats)]
     lib.icpk_align_batch.argtypes = [C.c_void_p, C.c_int32, C.POINTER(Pair), C.POINTER(Params), fp, C.POINTER(Stats)]
@@ -249,10 +254,19 @@ class Context:
     def reset_source(self):
         self._chk(self._lib.icpk_reset_source(self._h))
 
+    def commit_source(self):
+        self._chk(self._lib.icpk_commit_source(self._h))
+
     def get_source(self):
         n = self._lib.icpk_source_size(self._h)
         out = np.empty((3, n), np.float32)
         self._chk(self._lib.icpk_get_source(self._h, _fp(out[0]), _fp(out[1]), _fp(out[2])))
+        return out
+
+    def get_target(self):
+        n = self._lib.icpk_target_size(self._h)
+        out = np.empty((3, n), np.float32)
+        self._chk(self._lib.icpk_get_target(self._h, _fp(out[0]), _fp(out[1]), _fp(out[2])))
         return out
 
     @property
@@ -291,6 +305,23 @@ class Context:
         R = _f(R).reshape(9)
         t = _f(t).reshape(3)
         self._chk(self._lib.icpk_transform_source(self._h, _fp(R), _fp(t)))
+
+    def transform_target(self, R, t):
+        R = _f(R).reshape(9)
+        t = _f(t).reshape(3)
+        self._chk(self._lib.icpk_transform_target(self._h, _fp(R), _fp(t)))
+
+    def get_trace(self, max_iterations=64):
+        n = C.c_int32(0)
+        R = np.zeros((max_iterations, 9), np.float32)
+        t = np.zeros((max_iterations, 3), np.float32)
+        pairs = np.zeros(max_iterations, np.int32)
+        mse = np.zeros(max_iterations, np.float32)
+        self._chk(self._lib.icpk_get_trace(self._h, C.byref(n), _fp(R), _fp(t),
+                                           pairs.ctypes.data_as(C.POINTER(C.c_int32)), _fp(mse)))
+        k = n.value
+        return [dict(R=R[i].reshape(3, 3).copy(), t=t[i].copy(), n_pairs=int(pairs[i]), mse=np.float32(mse[i]))
+                for i in range(k)]
 
     def pair_distance(self, a, b):
         a = _f(a)

@@ -45,5 +45,23 @@ def build(force=False, verbose=False, extra=()):
     return LIB
 
 
+CPP_TEST = os.path.join(LIBDIR, "test_icp_align")
+
+
+def build_cpp_test(force=False):
+    """Host-only C++ program over icp_align.hpp + the C ABI (g++, links -licpk)."""
+    src = os.path.join(ROOT, "tests", "cpp", "test_icp_align.cpp")
+    hdr = os.path.join(HERE, "include", "icp_align.hpp")
+    build()
+    newest = max(os.path.getmtime(p) for p in (src, hdr, LIB))
+    if not force and os.path.exists(CPP_TEST) and os.path.getmtime(CPP_TEST) >= newest:
+        return CPP_TEST
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-I", os.path.join(ROOT, "include"), "-I",
+                           os.path.join(HERE, "include"), src, "-L", LIBDIR, "-licpk", "-Wl,-rpath,$ORIGIN",
+                           "-Wl,-rpath-link,/opt/rocm/lib", "-o", CPP_TEST])
+    return CPP_TEST
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_cpp_test(force="--force" in sys.argv))

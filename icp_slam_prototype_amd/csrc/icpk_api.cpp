@@ -58,6 +58,8 @@ struct icpk_ctx {
   int bp_counts_cap = 0;
   int* bp_n_host = nullptr;  // pinned
   std::vector<hipEvent_t> events;
+  std::vector<float> trace_R, trace_t, trace_mse;  // per-iteration record of the last align
+  std::vector<int32_t> trace_pairs;
   int target_blocks = 16384;
   int q_per_lane = 0;  // 0 = auto
   std::string err;
@@ -280,7 +282,7 @@ void icpk_default_params(icpk_params* p) {
   p->max_nn_dist = ICPK_MAX_NN_DISTANCE;
   p->min_pairs = ICPK_MIN_PAIRS;
   p->solve = ICPK_SOLVE_REFERENCE;
-  p->nn_mode = ICPK_NN_EXACT;
+  p->nn_mode = ICPK_NN_FILTERED;  // same results as ICPK_NN_EXACT, ~5x faster
   p->last_rotation[0] = p->last_rotation[4] = p->last_rotation[8] = 1.f;
 }
 
@@ -394,6 +396,19 @@ int icpk_reset_source(icpk_ctx* ctx) {
   return ICPK_OK;
 }
 
+int icpk_commit_source(icpk_ctx* ctx) {
+  if (!ctx) return ICPK_E_ARG;
+  if (!ctx->have_src) return fail(ctx, ICPK_E_NOT_SET, "source cloud not set");
+  ICPK_HIP(ctx, hipSetDevice(ctx->device));
+  const Cloud &a = ctx->src, &b = ctx->src0;  // src0.cap >= src.cap by construction
+  const int m = round_up(a.n < 1 ? 1 : a.n, NN_TILE);
+  ICPK_HIP(ctx, hipMemcpyAsync(b.x(), a.x(), (size_t)m * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+  ICPK_HIP(ctx, hipMemcpyAsync(b.y(), a.y(), (size_t)m * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+  ICPK_HIP(ctx, hipMemcpyAsync(b.z(), a.z(), (size_t)m * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+  ICPK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return ICPK_OK;
+}
+
 int icpk_get_source(icpk_ctx* ctx, float* x, float* y, float* z) {
   if (!ctx || !x || !y || !z) return ICPK_E_ARG;
   if (!ctx->have_src) return fail(ctx, ICPK_E_NOT_SET, "source cloud not set");
@@ -403,6 +418,20 @@ int icpk_get_source(icpk_ctx* ctx, float* x, float* y, float* z) {
     ICPK_HIP(ctx, hipMemcpyAsync(x, ctx->src.x(), b, hipMemcpyDeviceToHost, ctx->stream));
     ICPK_HIP(ctx, hipMemcpyAsync(y, ctx->src.y(), b, hipMemcpyDeviceToHost, ctx->stream));
     ICPK_HIP(ctx, hipMemcpyAsync(z, ctx->src.z(), b, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  ICPK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return ICPK_OK;
+}
+
+int icpk_get_target(icpk_ctx* ctx, float* x, float* y, float* z) {
+  if (!ctx || !x || !y || !z) return ICPK_E_ARG;
+  if (!ctx->have_tgt) return fail(ctx, ICPK_E_NOT_SET, "target cloud not set");
+  ICPK_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t b = (size_t)ctx->tgt.n * sizeof(float);
+  if (b) {
+    ICPK_HIP(ctx, hipMemcpyAsync(x, ctx->tgt.x(), b, hipMemcpyDeviceToHost, ctx->stream));
+    ICPK_HIP(ctx, hipMemcpyAsync(y, ctx->tgt.y(), b, hipMemcpyDeviceToHost, ctx->stream));
+    ICPK_HIP(ctx, hipMemcpyAsync(z, ctx->tgt.z(), b, hipMemcpyDeviceToHost, ctx->stream));
   }
   ICPK_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return ICPK_OK;
@@ -468,6 +497,39 @@ int icpk_transform_source(icpk_ctx* ctx, const float R[9], const float t[3]) {
   ICPK_HIP(ctx, hipGetLastError());
   ctx->have_assoc = false;
   ICPK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return ICPK_OK;
+}
+
+int icpk_transform_target(icpk_ctx* ctx, const float R[9], const float t[3]) {
+  if (!ctx || !R || !t) return ICPK_E_ARG;
+  if (!ctx->have_tgt) return fail(ctx, ICPK_E_NOT_SET, "target cloud not set");
+  ICPK_HIP(ctx, hipSetDevice(ctx->device));
+  Rt rt;
+  std::memcpy(rt.R, R, sizeof(rt.R));
+  std::memcpy(rt.t, t, sizeof(rt.t));
+  Cloud& c = ctx->tgt;
+  launch_transform(c.x(), c.y(), c.z(), c.n, rt, ctx->stream);
+  // the kernel works on whole float4s: restore the +inf padding it touched
+  const int padded = round_up(c.n < 1 ? 1 : c.n, NN_TILE);
+  launch_fill_f32(c.x() + c.n, padded - c.n, __builtin_inff(), ctx->stream);
+  launch_fill_f32(c.y() + c.n, padded - c.n, __builtin_inff(), ctx->stream);
+  launch_fill_f32(c.z() + c.n, padded - c.n, __builtin_inff(), ctx->stream);
+  ICPK_HIP(ctx, hipGetLastError());
+  ctx->have_assoc = false;
+  ctx->have_dec = false;
+  ctx->have_seed = false;
+  ICPK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return ICPK_OK;
+}
+
+int icpk_get_trace(icpk_ctx* ctx, int32_t* n_iter, float* R_out, float* t_out, int32_t* pairs_out, float* mse_out) {
+  if (!ctx || !n_iter) return ICPK_E_ARG;
+  const size_t n = ctx->trace_R.size() / 9;  // completed solves (a fallback iteration records none)
+  *n_iter = (int32_t)n;
+  if (R_out && n) std::memcpy(R_out, ctx->trace_R.data(), n * 9 * sizeof(float));
+  if (t_out && n) std::memcpy(t_out, ctx->trace_t.data(), n * 3 * sizeof(float));
+  if (pairs_out && n) std::memcpy(pairs_out, ctx->trace_pairs.data(), n * sizeof(int32_t));
+  if (mse_out && n) std::memcpy(mse_out, ctx->trace_mse.data(), n * sizeof(float));
   return ICPK_OK;
 }
 
@@ -543,6 +605,10 @@ int icpk_align(icpk_ctx* ctx, const icpk_params* p, float T_out[16], icpk_stats*
     return stamp(nullptr);
   };
 
+  ctx->trace_R.clear();
+  ctx->trace_t.clear();
+  ctx->trace_mse.clear();
+  ctx->trace_pairs.clear();
   ctx->log_last = std::chrono::steady_clock::now();
   rc = sweep();  // icp.cpp:98
   if (rc) return rc;
@@ -560,6 +626,8 @@ int icpk_align(icpk_ctx* ctx, const icpk_params* p, float T_out[16], icpk_stats*
       status = ICPK_W_TOO_FEW_PAIRS;
       break;
     }
+    ctx->trace_pairs.push_back((int32_t)npairs);
+    ctx->trace_mse.push_back(mse);
     if (p->solve == ICPK_SOLVE_REFERENCE) {
       float M[9], R[9], Rinv[9], neg[3];
       for (int k = 0; k < 9; ++k) M[k] = (float)sums[k];  // icp.cpp:212 (CV_32F result)
@@ -577,6 +645,8 @@ int icpk_align(icpk_ctx* ctx, const icpk_params* p, float T_out[16], icpk_stats*
       }
       rc = apply(Rinv, neg);  // icp.cpp:236,245
       if (rc) return rc;
+      ctx->trace_R.insert(ctx->trace_R.end(), R, R + 9);
+      ctx->trace_t.insert(ctx->trace_t.end(), offset, offset + 3);
     } else {
       double sa[3], sb[3], sab[9], Rd[9], td[3];
       for (int k = 0; k < 3; ++k) {
@@ -593,6 +663,8 @@ int icpk_align(icpk_ctx* ctx, const icpk_params* p, float T_out[16], icpk_stats*
       for (int k = 0; k < 3; ++k) tf[k] = (float)td[k];
       rc = apply(Rf, tf);
       if (rc) return rc;
+      ctx->trace_R.insert(ctx->trace_R.end(), Rf, Rf + 9);
+      ctx->trace_t.insert(ctx->trace_t.end(), tf, tf + 3);
       double Tn[12];
       for (int r = 0; r < 3; ++r)
         for (int c = 0; c < 4; ++c) {

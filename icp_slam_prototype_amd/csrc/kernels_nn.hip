@@ -153,12 +153,13 @@ __device__ __forceinline__ float filt_threshold(float d) {
   return (t == t) ? t : __builtin_inff();  // NaN best (garbage input): pass everything
 }
 
-// fast path for one group of NNF_G wave-uniform targets: returns, per query of this
-// lane, the smallest fp32 estimate e over the group (v_min3_f32 folds two per op)
+// fast path for one group of NNF_G wave-uniform targets: the fp32 estimates e[k][u]
+// of every (target k, query u of this lane) and their minimum per query
+// (v_min3_f32 folds two estimates per instruction)
 template <int Q>
-__device__ __forceinline__ void group_min(const float (&qx)[Q], const float (&qy)[Q], const float (&qz)[Q],
-                                          const float (&X)[NNF_G], const float (&Y)[NNF_G], const float (&Z)[NNF_G],
-                                          float (&m)[Q]) {
+__device__ __forceinline__ void group_estimates(const float (&qx)[Q], const float (&qy)[Q], const float (&qz)[Q],
+                                                const float (&X)[NNF_G], const float (&Y)[NNF_G],
+                                                const float (&Z)[NNF_G], float (&e)[NNF_G][Q], float (&m)[Q]) {
 #pragma unroll
   for (int u = 0; u < Q; ++u) m[u] = __builtin_inff();
 #pragma unroll
@@ -167,31 +168,38 @@ __device__ __forceinline__ void group_min(const float (&qx)[Q], const float (&qy
     for (int u = 0; u < Q; ++u) {
       const float dx0 = qx[u] - X[k], dy0 = qy[u] - Y[k], dz0 = qz[u] - Z[k];
       const float dx1 = qx[u] - X[k + 1], dy1 = qy[u] - Y[k + 1], dz1 = qz[u] - Z[k + 1];
-      const float e0 = __builtin_fmaf(dz0, dz0, __builtin_fmaf(dy0, dy0, dx0 * dx0));
-      const float e1 = __builtin_fmaf(dz1, dz1, __builtin_fmaf(dy1, dy1, dx1 * dx1));
-      m[u] = __builtin_fminf(m[u], __builtin_fminf(e0, e1));
+      e[k][u] = __builtin_fmaf(dz0, dz0, __builtin_fmaf(dy0, dy0, dx0 * dx0));
+      e[k + 1][u] = __builtin_fmaf(dz1, dz1, __builtin_fmaf(dy1, dy1, dx1 * dx1));
+      m[u] = __builtin_fminf(m[u], __builtin_fminf(e[k][u], e[k + 1][u]));
     }
   }
 }
 
-// slow path: exact re-evaluation of the whole group, lexicographic (d, j) merge
+// slow path, entered when some lane's minimum passed its threshold: walk the group
+// and re-evaluate exactly only those targets some lane still passes (wave-uniform
+// branch per target); lexicographic (d, j) merge; thresholds tighten as we go
 template <int Q>
 __device__ __forceinline__ void group_exact(const float (&qx)[Q], const float (&qy)[Q], const float (&qz)[Q],
                                             const float (&X)[NNF_G], const float (&Y)[NNF_G], const float (&Z)[NNF_G],
-                                            int j, float (&bd)[Q], int (&bj)[Q], float (&T)[Q]) {
+                                            const float (&e)[NNF_G][Q], int j, float (&bd)[Q], int (&bj)[Q],
+                                            float (&T)[Q]) {
 #pragma unroll
   for (int k = 0; k < NNF_G; ++k) {
+    bool hit = false;
 #pragma unroll
-    for (int u = 0; u < Q; ++u) {
-      const float d = pair_dist(qx[u], qy[u], qz[u], X[k], Y[k], Z[k]);
-      const int jj = j + k;
-      const bool up = (d < bd[u]) | ((d == bd[u]) & (jj < bj[u]));
-      bd[u] = up ? d : bd[u];
-      bj[u] = up ? jj : bj[u];
+    for (int u = 0; u < Q; ++u) hit |= (e[k][u] <= T[u]);
+    if (__builtin_amdgcn_ballot_w64(hit) != 0) {
+#pragma unroll
+      for (int u = 0; u < Q; ++u) {
+        const float d = pair_dist(qx[u], qy[u], qz[u], X[k], Y[k], Z[k]);
+        const int jj = j + k;
+        const bool up = (d < bd[u]) | ((d == bd[u]) & (jj < bj[u]));
+        bd[u] = up ? d : bd[u];
+        bj[u] = up ? jj : bj[u];
+        T[u] = up ? filt_threshold(d) : T[u];
+      }
     }
   }
-#pragma unroll
-  for (int u = 0; u < Q; ++u) T[u] = filt_threshold(bd[u]);
 }
 
 template <int Q>
@@ -244,24 +252,24 @@ __global__ __launch_bounds__(NN_THREADS) void nn_filtered_kernel(
       YB[k] = typ[j + NNF_G + k];
       ZB[k] = tzp[j + NNF_G + k];
     }
-    float m[Q];
+    float e[NNF_G][Q], m[Q];
     bool hit;
-    group_min<Q>(qx, qy, qz, XA, YA, ZA, m);
+    group_estimates<Q>(qx, qy, qz, XA, YA, ZA, e, m);
     hit = false;
 #pragma unroll
     for (int u = 0; u < Q; ++u) hit |= (m[u] <= T[u]);
-    if (__builtin_amdgcn_ballot_w64(hit) != 0) group_exact<Q>(qx, qy, qz, XA, YA, ZA, j, bd, bj, T);
+    if (__builtin_amdgcn_ballot_w64(hit) != 0) group_exact<Q>(qx, qy, qz, XA, YA, ZA, e, j, bd, bj, T);
 #pragma unroll
     for (int k = 0; k < NNF_G; ++k) {
       XA[k] = txp[j + 2 * NNF_G + k];
       YA[k] = typ[j + 2 * NNF_G + k];
       ZA[k] = tzp[j + 2 * NNF_G + k];
     }
-    group_min<Q>(qx, qy, qz, XB, YB, ZB, m);
+    group_estimates<Q>(qx, qy, qz, XB, YB, ZB, e, m);
     hit = false;
 #pragma unroll
     for (int u = 0; u < Q; ++u) hit |= (m[u] <= T[u]);
-    if (__builtin_amdgcn_ballot_w64(hit) != 0) group_exact<Q>(qx, qy, qz, XB, YB, ZB, j + NNF_G, bd, bj, T);
+    if (__builtin_amdgcn_ballot_w64(hit) != 0) group_exact<Q>(qx, qy, qz, XB, YB, ZB, e, j + NNF_G, bd, bj, T);
   }
 
 #pragma unroll

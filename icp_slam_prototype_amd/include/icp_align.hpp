@@ -1,0 +1,201 @@
+// icp_align.hpp -- C++ host side above the C ABI (include/icpk.h).
+//
+// Mirrors the reference's operator surface for the ICP path without OpenCV:
+//   * icp::align(source, target, params, &result)      -- the inner loop on SoA views
+//   * icp::Tracker                                     -- the per-frame state machine of
+//     icp::getTransformation (icp.cpp:22-26 file-scope pose state, :38-71 cloud set-up,
+//     :98-268 loop, :237/:246 pose update), fed with raw CV_16UC1 depth buffers
+//   * icp::makeRotationMatrix / meanSquareError / toEulerianAngle helpers with the
+//     reference's names and argument meaning (icp.hpp:25-27, SLAM.hpp:44-46)
+// icp_opencv_adapter.hpp adds the exact cv::Mat signature when OpenCV is present.
+//
+// Header-only; link with -licpk.  Errors: status codes of icpk.h, never exceptions
+// from the hot path (the Engine constructor throws std::runtime_error when no GPU
+// is usable -- there is no CPU fallback).
+#pragma once
+#include <cstdint>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "icpk.h"
+
+namespace icp {
+
+// xyz structure-of-arrays view of a point cloud in host memory (replaces
+// point_list_t / color_point_t, pointcloud.hpp:13-23; colour weight is 0)
+struct CloudView {
+  const float* x = nullptr;
+  const float* y = nullptr;
+  const float* z = nullptr;
+  int32_t n = 0;
+};
+
+struct AlignParams : icpk_params {
+  AlignParams() { icpk_default_params(this); }
+};
+
+struct AlignResult {
+  float T[16];        // row-major 4x4, same content as the cv::Mat of icp.cpp:29,284
+  icpk_stats stats{};
+  int status = ICPK_OK;
+  float (*rotation())[4] { return reinterpret_cast<float(*)[4]>(T); }
+};
+
+// RAII owner of one icpk_ctx (one GPU, one HIP stream).  One Engine per host
+// thread / per GPU; calls on one Engine are serialised.
+class Engine {
+ public:
+  explicit Engine(int device = 0) {
+    const int rc = icpk_create(&ctx_, device);
+    if (rc != ICPK_OK) throw std::runtime_error("icpk_create failed (status " + std::to_string(rc) + "): no usable HIP device");
+  }
+  ~Engine() { icpk_destroy(ctx_); }
+  Engine(const Engine&) = delete;
+  Engine& operator=(const Engine&) = delete;
+  icpk_ctx* ctx() const { return ctx_; }
+  const char* last_error() const { return icpk_last_error(ctx_); }
+
+ private:
+  icpk_ctx* ctx_ = nullptr;
+};
+
+// The inner loop on explicit clouds (frame-pair formulation of icp.cpp:98-268).
+inline int align(Engine& eng, const CloudView& source, const CloudView& target, const AlignParams& params,
+                 AlignResult* out) {
+  if (!out) return ICPK_E_ARG;
+  int rc = icpk_set_target(eng.ctx(), target.x, target.y, target.z, target.n);
+  if (rc == ICPK_OK) rc = icpk_set_source(eng.ctx(), source.x, source.y, source.z, source.n);
+  if (rc != ICPK_OK) {
+    for (int k = 0; k < 16; ++k) out->T[k] = (k % 5 == 0) ? 1.f : 0.f;
+    out->status = rc;
+    return rc;
+  }
+  out->status = icpk_align(eng.ctx(), &params, out->T, &out->stats);
+  return out->status;
+}
+
+// icp.cpp:640-653
+inline void makeRotationMatrix(float x, float y, float z, float out[9]) { icpk_make_rotation_matrix(x, y, z, out); }
+
+// icp.cpp:622-638: (mean error)^2, sequential float accumulation like the reference
+inline float meanSquareError(const std::vector<float>& errors) {
+  float s = 0.f;
+  for (float e : errors) s += e;
+  if (!errors.empty()) {
+    s /= (float)errors.size();
+    s = (float)((double)s * (double)s);
+  }
+  return s;
+}
+
+// quaternion.cpp:23-79 + SLAM.cpp:613-636: rotation matrix -> roll/pitch/yaw degrees
+inline void toEulerianAngle(const float rotation[9], float& x, float& y, float& z) {
+  float q[4], e[3];
+  icpk_matrix_to_quaternion(rotation, q);
+  icpk_quaternion_to_euler(q, e);
+  x = e[0];
+  y = e[1];
+  z = e[2];
+}
+
+// The state icp.cpp keeps at file scope (cameraRotation, lastRotation,
+// cameraPosition, lastTranslation, icp.cpp:22-25) plus the per-frame procedure of
+// getTransformation, with the accumulated key-point map replaced by the previous
+// frame's full cloud (the association the reference keeps commented at
+// icp.cpp:253).  Depth buffers are CV_16UC1 row-major (rows x cols uint16).
+class Tracker {
+ public:
+  explicit Tracker(Engine& eng, float fx = ICPK_FX, float cx = ICPK_CX) : eng_(eng), fx_(fx), cx_(cx) { reset(); }
+
+  void reset() {
+    static const float I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    std::memcpy(cameraRotation, I, sizeof(I));  // icp.cpp:49
+    std::memcpy(lastRotation, I, sizeof(I));    // icp.cpp:50
+    cameraPosition[0] = cameraPosition[1] = cameraPosition[2] = 5.f;   // icp.cpp:53
+    lastTranslation[0] = lastTranslation[1] = lastTranslation[2] = 0.f;  // icp.cpp:54
+    params = AlignParams();
+    params.solve = ICPK_SOLVE_REFERENCE;
+  }
+
+  // Same meaning as icp::getTransformation(data, previous, ..., maxIterations, threshold):
+  // returns the status, writes the 4x4 into T (row-major).  `data` is the current
+  // frame, `previous` the frame before it.
+  int getTransformation(const uint16_t* data, const uint16_t* previous, int rows, int cols, int maxIterations,
+                        float threshold, float T[16]) {
+    icpk_ctx* c = eng_.ctx();
+    // icp.cpp:38-39: back-project both frames; :58-59 / :70-71: rotate by the camera
+    // rotation, translate by the camera position (both clouds get the current pose)
+    int n = icpk_backproject(c, previous, rows, cols, fx_, cx_, nullptr, 1);
+    if (n < 0) return n;
+    int rc = icpk_transform_target(c, cameraRotation, cameraPosition);
+    if (rc != ICPK_OK) return rc;
+    n = icpk_backproject(c, data, rows, cols, fx_, cx_, nullptr, 0);
+    if (n < 0) return n;
+    rc = icpk_transform_source(c, cameraRotation, cameraPosition);
+    if (rc != ICPK_OK) return rc;
+    params.max_iterations = maxIterations;
+    params.threshold = threshold;
+    std::memcpy(params.last_rotation, lastRotation, sizeof(lastRotation));
+    std::memcpy(params.last_translation, lastTranslation, sizeof(lastTranslation));
+    // the aligned source of icpk_align starts from the cloud "as uploaded"; make the
+    // posed cloud that starting point
+    rc = icpk_commit_source(c);
+    if (rc != ICPK_OK) return rc;
+    icpk_stats st;
+    rc = icpk_align(c, &params, T, &st);
+    if (rc < 0) return rc;
+    lastStats = st;
+    // pose bookkeeping exactly as the loop does it (icp.cpp:235-237, 245-246)
+    int32_t niter = 0;
+    std::vector<float> R((size_t)maxIterations * 9 + 9), t((size_t)maxIterations * 3 + 3);
+    icpk_get_trace(c, &niter, R.data(), t.data(), nullptr, nullptr);
+    for (int i = 0; i < niter; ++i) {
+      float Rinv[9], prod[9];
+      invert3(R.data() + 9 * i, Rinv);
+      mul3(cameraRotation, Rinv, prod);  // cameraRotation *= R
+      std::memcpy(cameraRotation, prod, sizeof(prod));
+      for (int k = 0; k < 3; ++k) cameraPosition[k] -= t[3 * i + k];  // cameraPosition -= offset
+    }
+    // icp.cpp:260-261: lastTranslation = -offset; lastRotation = R (the outer R: identity
+    // on the normal path because the inner R shadows it)
+    for (int k = 0; k < 3; ++k) lastTranslation[k] = -T[4 * k + 3];
+    if (rc != ICPK_W_TOO_FEW_PAIRS) {
+      static const float I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+      std::memcpy(lastRotation, I, sizeof(I));
+    }
+    return rc;
+  }
+
+  float cameraRotation[9];
+  float lastRotation[9];
+  float cameraPosition[3];
+  float lastTranslation[3];
+  AlignParams params;
+  icpk_stats lastStats{};
+
+ private:
+  static void mul3(const float A[9], const float B[9], float C[9]) {  // CV_32F product, double accumulate
+    for (int r = 0; r < 3; ++r)
+      for (int cc = 0; cc < 3; ++cc) {
+        double s = 0;
+        for (int k = 0; k < 3; ++k) s += (double)A[3 * r + k] * (double)B[3 * k + cc];
+        C[3 * r + cc] = (float)s;
+      }
+  }
+  static void invert3(const float m[9], float out[9]) {  // icp.cpp:235 Mat::inv on a 3x3
+    const double a = m[0], b = m[1], c = m[2], d = m[3], e = m[4], f = m[5], g = m[6], h = m[7], i = m[8];
+    const double det = a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g);
+    const double s = det != 0.0 ? 1.0 / det : 0.0;
+    const double t[9] = {(e * i - f * h) * s, (c * h - b * i) * s, (b * f - c * e) * s,
+                         (f * g - d * i) * s, (a * i - c * g) * s, (c * d - a * f) * s,
+                         (d * h - e * g) * s, (b * g - a * h) * s, (a * e - b * d) * s};
+    for (int k = 0; k < 9; ++k) out[k] = (float)t[k];
+  }
+
+  Engine& eng_;
+  float fx_, cx_;
+};
+
+}  // namespace icp

@@ -135,8 +135,13 @@ int icpk_set_target_device(icpk_ctx *ctx, const float *dx, const float *dy, cons
 int icpk_set_source_device(icpk_ctx *ctx, const float *dx, const float *dy, const float *dz, int32_t n);
 /* working copy of the source <- the cloud last given to icpk_set_source*     */
 int icpk_reset_source(icpk_ctx *ctx);
+/* the cloud icpk_align / icpk_reset_source start from <- the working copy (makes
+ * transforms applied with icpk_transform_source permanent; device-side copy) */
+int icpk_commit_source(icpk_ctx *ctx);
 /* current (transformed) source, to host */
 int icpk_get_source(icpk_ctx *ctx, float *x, float *y, float *z);
+/* target cloud as the device holds it (after icpk_transform_target / icpk_backproject) */
+int icpk_get_target(icpk_ctx *ctx, float *x, float *y, float *z);
 int32_t icpk_source_size(const icpk_ctx *ctx);
 int32_t icpk_target_size(const icpk_ctx *ctx);
 
@@ -155,6 +160,9 @@ int icpk_reduce(icpk_ctx *ctx, float max_dist, double *sums, int64_t *count);
 /* pointcloud.cpp:321-346 rotate + :349-359 translate:
  * p <- fl32(fl32(R p) + t), R row-major, applied to the working source. */
 int icpk_transform_source(icpk_ctx *ctx, const float R[9], const float t[3]);
+/* same transform applied to the target cloud (the reference moves the previous
+ * frame into the world frame the same way, icp.cpp:58-59) */
+int icpk_transform_target(icpk_ctx *ctx, const float R[9], const float t[3]);
 /* associations of the last sweep (device -> host) */
 int icpk_get_associations(icpk_ctx *ctx, int32_t *idx_out, float *dist_out);
 
@@ -164,6 +172,15 @@ int icpk_get_associations(icpk_ctx *ctx, int32_t *idx_out, float *dist_out);
  * matrix icp::getTransformation returns (icp.cpp:29,227-233,266-268) with row
  * 3 = (0,0,0,1) instead of uninitialised memory.  stats may be NULL. */
 int icpk_align(icpk_ctx *ctx, const icpk_params *p, float T_out[16], icpk_stats *stats);
+/* Per-iteration record of the last icpk_align: for iteration i < *n_iter,
+ * R_out[9*i..] is the rotation found (icp.cpp:218-223, before inversion),
+ * t_out[3*i..] the offset (reference flavour, icp.cpp:240) or translation
+ * (Kabsch), pairs_out[i] / mse_out[i] the association count and MSE the loop
+ * test at icp.cpp:155 saw.  The caller needs these to keep the reference's pose
+ * state (cameraRotation *= R^-1, cameraPosition -= offset, icp.cpp:237,246).
+ * Arrays sized for params.max_iterations entries; any may be NULL. */
+int icpk_get_trace(icpk_ctx *ctx, int32_t *n_iter, float *R_out, float *t_out, int32_t *pairs_out,
+                   float *mse_out);
 /* frame-batch mode: n_pairs independent pairs, one after the
  * other on this context's device; T_out n_pairs x 16, stats n_pairs (or NULL).
  * Returns the first negative status, else the max status. */

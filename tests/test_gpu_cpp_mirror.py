@@ -1,0 +1,75 @@
+"""The C++ host mirror (icp_slam_prototype_amd/include/icp_align.hpp): a sequence
+of depth frames through icp::Tracker -- the getTransformation-shaped entry point
+-- compared with the same procedure restated in Python over the oracle."""
+import os
+import struct
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+from icp_slam_prototype_amd import build, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def mul3f(A, B):
+    A = A.astype(np.float64)
+    B = B.astype(np.float64)
+    return ((A[:, 0:1] * B[0:1, :] + A[:, 1:2] * B[1:2, :]) + A[:, 2:3] * B[2:3, :]).astype(np.float32)
+
+
+def test_tracker_sequence_and_align(oracle):
+    exe = build.build_cpp_test()
+    rows, cols, max_iter, thr = 120, 160, 6, 1e-5
+    rng = np.random.default_rng(0)
+    frames = []
+    for k in range(3):  # camera drifting by 0.5 degree / 1 cm per frame
+        Rm = synth.rot_xyz_deg(0, 0.5 * k, 0)
+        d = synth.render_room_depth(rows, cols, Rm, np.array([0.01 * k, 0, 0]), noise_sigma=0.001, rng=rng)
+        d[rng.random(d.shape) > 0.5] = 0
+        frames.append(d.astype(np.uint16))
+    p = synth.frustum_pair(1500, seed=3, rot_deg=(0, 1, 0), shift=(0.01, 0, 0))
+    with tempfile.TemporaryDirectory() as td:
+        fin, fout = os.path.join(td, "in.bin"), os.path.join(td, "out.bin")
+        with open(fin, "wb") as f:
+            f.write(struct.pack("<4if", rows, cols, len(frames), max_iter, thr))
+            for d in frames:
+                f.write(d.tobytes())
+            f.write(struct.pack("<2i", p["source"].shape[1], p["target"].shape[1]))
+            f.write(np.ascontiguousarray(p["source"], np.float32).tobytes())
+            f.write(np.ascontiguousarray(p["target"], np.float32).tobytes())
+        subprocess.check_call([exe, fin, fout])
+        raw = open(fout, "rb").read()
+    off = 0
+    Rcam = np.eye(3, dtype=np.float32)
+    pcam = np.full(3, 5, np.float32)
+    lastR = np.eye(3, dtype=np.float32)
+    lastT = np.zeros(3, np.float32)
+    for i in range(1, len(frames)):
+        rc, iters = struct.unpack_from("<2i", raw, off)
+        off += 8
+        vals = np.frombuffer(raw, np.float32, 16 + 9 + 3 + 3, off)
+        off += 4 * 31
+        T, camR, camP, eul = vals[:16].reshape(4, 4), vals[16:25].reshape(3, 3), vals[25:28], vals[28:31]
+        # the same procedure over the oracle (icp.cpp:38-71, 98-268 frame-pair formulation)
+        tgt = oracle.transform_points(oracle.backproject(frames[i - 1]), Rcam, pcam)
+        src = oracle.transform_points(oracle.backproject(frames[i]), Rcam, pcam)
+        o = oracle.align(src, tgt, max_iterations=max_iter, threshold=thr, solve=0, sum_order=1, threads=4,
+                         last_rotation=lastR, last_translation=lastT)
+        assert rc == o["status"] and iters == o["iterations"] and iters > 0
+        assert np.linalg.norm(T.astype(np.float64) - o["T"].astype(np.float64)) < 1e-5
+        assert np.array_equal(T, o["T"])
+        for it in o["trace"]:
+            Rcam = mul3f(Rcam, oracle.inv3(it["R"]))
+            pcam = (pcam - it["t"]).astype(np.float32)
+        lastT = -o["T"][:3, 3]
+        assert np.array_equal(camR, Rcam) and np.array_equal(camP, pcam)
+        assert np.array_equal(eul, oracle.to_euler(oracle.quaternion_from_matrix(Rcam)))
+    rc, iters = struct.unpack_from("<2i", raw, off)
+    off += 8
+    T = np.frombuffer(raw, np.float32, 16, off).reshape(4, 4)
+    o = oracle.align(p["source"], p["target"], max_iterations=max_iter, solve=1, sum_order=1, fixed_iterations=True,
+                     threads=4)
+    assert rc == 0 and iters == max_iter and np.array_equal(T, o["T"])

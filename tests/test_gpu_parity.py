@@ -430,3 +430,30 @@ def test_full_size_kinect_pair_properties(ctx):
     T1, st1, _ = ctx.align(max_iterations=3, fixed_iterations=1, nn_mode=binding.NN_EXACT)
     T2, st2, _ = ctx.align(max_iterations=3, fixed_iterations=1, nn_mode=binding.NN_FILTERED)
     assert np.array_equal(T1, T2) and st1.final_pairs == st2.final_pairs and st1.final_mse == st2.final_mse
+
+
+def test_transform_target_commit_and_trace(ctx, oracle):
+    rng = np.random.default_rng(12)
+    tgt = (rng.uniform(-2, 2, (3, 1500)) + 5).astype(np.float32)
+    src = (tgt[:, :1200] + rng.normal(0, 0.01, (3, 1200))).astype(np.float32)
+    R = oracle.make_rotation_matrix(1, 2, 3)
+    t = np.array([0.5, -0.25, 0.125], np.float32)
+    ctx.set_target(tgt)
+    ctx.set_source(src)
+    ctx.transform_target(R, t)
+    ctx.transform_source(R, t)
+    tgt2, src2 = oracle.transform_points(tgt, R, t), oracle.transform_points(src, R, t)
+    assert np.array_equal(ctx.get_target(), tgt2) and np.array_equal(ctx.get_source(), src2)
+    idx, dist = ctx.nn()  # the +inf padding of the target survived the transform
+    oidx, odist = oracle.nn_bruteforce(src2, tgt2)
+    assert np.array_equal(idx, oidx) and np.array_equal(dist, odist)
+    ctx.commit_source()
+    ctx.reset_source()
+    assert np.array_equal(ctx.get_source(), src2)
+    T, st, rc = ctx.align(max_iterations=5, fixed_iterations=1, solve=binding.SOLVE_REFERENCE)
+    o = oracle.align(src2, tgt2, max_iterations=5, solve=0, sum_order=1, fixed_iterations=True)
+    tr = ctx.get_trace()
+    assert len(tr) == len(o["trace"]) == 5
+    for a, b in zip(tr, o["trace"]):
+        assert np.array_equal(a["R"], b["R"]) and np.array_equal(a["t"], b["t"])
+        assert a["n_pairs"] == b["n_pairs"] and a["mse"] == b["mse"]
