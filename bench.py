@@ -46,8 +46,8 @@ def parse():
     ap.add_argument("--workload", default="kinect640x480_30pct",
                     choices=["kinect640x480_30pct", "kinect640x480_dense", "kinect_v2_512x424", "dense1m", "frustum10k"])
     ap.add_argument("--solve", default="reference", choices=["reference", "kabsch"])
-    ap.add_argument("--nn-mode", default="filtered", choices=["exact", "filtered"],
-                    help="filtered (default, the product default) and exact give bit-identical results")
+    ap.add_argument("--nn-mode", default="pruned", choices=["exact", "filtered", "pruned"],
+                    help="all three give bit-identical results; pruned is the product default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=32768, help="queries in the CPU baseline sample")
     return ap.parse_args()
@@ -146,7 +146,7 @@ def main():
     params = binding.default_params(
         max_iterations=args.iters, fixed_iterations=1, profile=1,
         solve=binding.SOLVE_REFERENCE if args.solve == "reference" else binding.SOLVE_KABSCH,
-        nn_mode=binding.NN_EXACT if args.nn_mode == "exact" else binding.NN_FILTERED)
+        nn_mode={"exact": binding.NN_EXACT, "filtered": binding.NN_FILTERED, "pruned": binding.NN_PRUNED}[args.nn_mode])
 
     def sync_all():
         torch.cuda.synchronize()
@@ -209,7 +209,8 @@ def main():
             "nn_gpairs_per_s_wall": total_pairs / elapsed / 1e9,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "nn_exact_kernel" if args.nn_mode == "exact" else "nn_filtered_kernel",
+                         "kernel": {"exact": "nn_exact_kernel", "filtered": "nn_filtered_kernel<Q,false>",
+                                    "pruned": "nn_filtered_kernel<Q,true>"}[args.nn_mode],
                          "avg_launch_ms": avg_nn_s * 1e3, "algorithmic_bytes_per_launch": alg_bytes,
                          "gpairs_per_s_kernel": nq * nt / avg_nn_s / 1e9,
                          "note": "algorithmic operand bytes (LDS tiling re-uses each target tile across 256 "

@@ -16,7 +16,7 @@ OK = 0
 W_TOO_FEW_PAIRS = 1
 E_ARG, E_EMPTY_TARGET, E_HIP, E_NOT_SET, E_NO_DEVICE = -1, -2, -3, -4, -5
 SOLVE_REFERENCE, SOLVE_KABSCH = 0, 1
-NN_EXACT, NN_FILTERED = 0, 1
+NN_EXACT, NN_FILTERED, NN_PRUNED = 0, 1, 2
 NSUM = 19
 
 # every symbol include/icpk.h declares (tests/test_abi.py checks the header against this list)

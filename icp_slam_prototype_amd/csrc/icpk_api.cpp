@@ -42,6 +42,9 @@ struct icpk_ctx {
   Cloud dec;  // every NN_SEED_STRIDE-th target (seeding pre-pass of the filtered NN)
   bool have_tgt = false, have_src = false, have_assoc = false;
   bool have_dec = false;   // dec matches tgt
+  bool have_boxes = false; // boxes match tgt
+  float* boxes = nullptr;  // [6][tbox_stride] tile boxes then [6][sbox_stride] sub-tile boxes
+  int boxes_tiles_cap = 0;
   bool have_seed = false;  // `best` holds matches of a previous sweep of the same clouds
   nn_key_t* best = nullptr;
   nn_key_t* seed = nullptr;
@@ -181,7 +184,8 @@ int check_ready(icpk_ctx* ctx) {
 
 // enqueue one NN sweep (K1) over the working source
 int enqueue_nn(icpk_ctx* ctx, int nn_mode) {
-  if (nn_mode != ICPK_NN_EXACT && nn_mode != ICPK_NN_FILTERED) return fail(ctx, ICPK_E_ARG, "unknown nn_mode");
+  if (nn_mode != ICPK_NN_EXACT && nn_mode != ICPK_NN_FILTERED && nn_mode != ICPK_NN_PRUNED)
+    return fail(ctx, ICPK_E_ARG, "unknown nn_mode");
   const int nq = ctx->src.n;
   int rc = ensure_assoc(ctx, nq);
   if (rc) return rc;
@@ -238,11 +242,32 @@ int enqueue_nn(icpk_ctx* ctx, int nn_mode) {
       launch_nn_exact(c, ctx->stream);
       seed_scale = NN_SEED_STRIDE;
     }
+    NnBoxes bx;
+    const NnBoxes* pbx = nullptr;
+    if (nn_mode == ICPK_NN_PRUNED) {
+      if (ntiles > ctx->boxes_tiles_cap) {
+        if (ctx->boxes) ICPK_HIP(ctx, hipFree(ctx->boxes));
+        ctx->boxes = nullptr;
+        ctx->boxes_tiles_cap = 0;
+        ICPK_HIP(ctx, hipMalloc((void**)&ctx->boxes, (size_t)6 * (ntiles + 16) * (1 + NN_SUBS) * sizeof(float)));
+        ctx->boxes_tiles_cap = ntiles;
+        ctx->have_boxes = false;
+      }
+      bx.tbox_stride = ctx->boxes_tiles_cap + 16;
+      bx.sbox_stride = (ctx->boxes_tiles_cap + 16) * NN_SUBS;
+      bx.tbox = ctx->boxes;
+      bx.sbox = ctx->boxes + (size_t)6 * bx.tbox_stride;
+      if (!ctx->have_boxes) {
+        launch_tile_boxes(a.tx, a.ty, a.tz, ctx->tgt.n, ntiles, bx, ctx->stream);
+        ctx->have_boxes = true;
+      }
+      pbx = &bx;
+    }
     const int q = ctx->q_per_lane > 0 ? ctx->q_per_lane : (nq >= 65536 ? 2 : 1);
     a.tiles_per_chunk = chunking((nq + NN_THREADS * q - 1) / (NN_THREADS * q), ntiles);
     a.best = ctx->best;
     launch_fill_u64(ctx->best, nq, NN_KEY_INIT, ctx->stream);
-    launch_nn_filtered(a, ctx->seed, seed_scale, q, ctx->stream);
+    launch_nn_filtered(a, ctx->seed, seed_scale, q, pbx, ctx->stream);
   }
   ICPK_HIP(ctx, hipGetLastError());
   ctx->have_assoc = true;
@@ -282,7 +307,7 @@ void icpk_default_params(icpk_params* p) {
   p->max_nn_dist = ICPK_MAX_NN_DISTANCE;
   p->min_pairs = ICPK_MIN_PAIRS;
   p->solve = ICPK_SOLVE_REFERENCE;
-  p->nn_mode = ICPK_NN_FILTERED;  // same results as ICPK_NN_EXACT, ~5x faster
+  p->nn_mode = ICPK_NN_PRUNED;  // same results as ICPK_NN_EXACT (tests), fastest
   p->last_rotation[0] = p->last_rotation[4] = p->last_rotation[8] = 1.f;
 }
 
@@ -323,7 +348,7 @@ void icpk_destroy(icpk_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   for (hipEvent_t e : ctx->events) (void)hipEventDestroy(e);
-  void* dev[] = {ctx->dec.base, ctx->tgt.base, ctx->src0.base, ctx->src.base, ctx->best,      ctx->seed,     ctx->idx,
+  void* dev[] = {ctx->boxes, ctx->dec.base, ctx->tgt.base, ctx->src0.base, ctx->src.base, ctx->best,      ctx->seed,     ctx->idx,
                  ctx->dist,     ctx->partial,   ctx->pcount,   ctx->red_out,   ctx->depth_dev, ctx->bp_counts};
   for (void* p : dev)
     if (p) (void)hipFree(p);
@@ -353,6 +378,7 @@ static int set_target_impl(icpk_ctx* ctx, const float* x, const float* y, const 
   ctx->have_tgt = true;
   ctx->have_assoc = false;
   ctx->have_dec = false;
+  ctx->have_boxes = false;
   ctx->have_seed = false;
   return ICPK_OK;
 }
@@ -517,6 +543,7 @@ int icpk_transform_target(icpk_ctx* ctx, const float R[9], const float t[3]) {
   ICPK_HIP(ctx, hipGetLastError());
   ctx->have_assoc = false;
   ctx->have_dec = false;
+  ctx->have_boxes = false;
   ctx->have_seed = false;
   ICPK_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return ICPK_OK;
@@ -775,7 +802,7 @@ int icpk_backproject(icpk_ctx* ctx, const uint16_t* depth, int32_t rows, int32_t
   ICPK_HIP(ctx, hipGetLastError());
   ctx->have_assoc = false;
   ctx->have_seed = false;
-  if (which == 1) ctx->have_dec = false;
+  if (which == 1) ctx->have_dec = ctx->have_boxes = false;
   if (which == 0) {
     ctx->have_src = true;
     rc = copy_src0_to_src(ctx);

@@ -52,7 +52,21 @@ inline int red_blocks(int n) {
 // kernels_nn.hip
 void launch_fill_u64(nn_key_t* p, int n, nn_key_t v, hipStream_t s);
 void launch_nn_exact(const NnArgs& a, hipStream_t s);
-void launch_nn_filtered(const NnArgs& a, const nn_key_t* seed, int seed_scale, int q_per_lane, hipStream_t s);
+// bounding boxes for the pruned scan: 6 planes (lo x,y,z, hi x,y,z) per 1024-target
+// tile (tbox) and per 128-target sub-tile (sbox)
+constexpr int NN_SUB = 128;
+constexpr int NN_SUBS = NN_TILE / NN_SUB;  // 8 sub-tiles per tile
+struct NnBoxes {
+  float* tbox;
+  int tbox_stride;  // floats per plane
+  float* sbox;
+  int sbox_stride;
+};
+// boxes == nullptr: brute force over every target
+void launch_nn_filtered(const NnArgs& a, const nn_key_t* seed, int seed_scale, int q_per_lane, const NnBoxes* boxes,
+                        hipStream_t s);
+void launch_tile_boxes(const float* x, const float* y, const float* z, int n, int ntiles, const NnBoxes& b,
+                       hipStream_t s);
 void launch_decimate(const float* x, const float* y, const float* z, int n, int stride, float* ox, float* oy, float* oz,
                      int n_out_pad, hipStream_t s);
 constexpr int NN_SEED_STRIDE = 16;  // decimation of the target for the seeding pre-pass

@@ -202,42 +202,15 @@ __device__ __forceinline__ void group_exact(const float (&qx)[Q], const float (&
   }
 }
 
+// scan targets [j0, j1) (multiples of 2*NNF_G) for the Q queries of this lane.
+// Two SGPR buffers (A, B) of NNF_G targets: the scalar loads of one group are in
+// flight while the other is consumed.  The last prefetch reads NNF_G floats past
+// j1; every cloud allocation carries that much slack.
 template <int Q>
-__global__ __launch_bounds__(NN_THREADS) void nn_filtered_kernel(
-    const float* __restrict__ qxp, const float* __restrict__ qyp, const float* __restrict__ qzp, int nq,
-    const float* __restrict__ txp, const float* __restrict__ typ, const float* __restrict__ tzp, int nt_pad,
-    int tiles_per_chunk, const nn_key_t* __restrict__ seed, int seed_scale, nn_key_t* __restrict__ best) {
-  const int tid = threadIdx.x;
-  const int ibase = blockIdx.x * (NN_THREADS * Q) + tid;
-  float qx[Q], qy[Q], qz[Q], bd[Q], T[Q];
-  int bj[Q];
-  nn_key_t key0[Q];
-#pragma unroll
-  for (int u = 0; u < Q; ++u) {
-    const int i = ibase + u * NN_THREADS;
-    const bool live = i < nq;
-    qx[u] = live ? qxp[i] : 0.f;
-    qy[u] = live ? qyp[i] : 0.f;
-    qz[u] = live ? qzp[i] : 0.f;
-    int js = live ? (int)(unsigned)(seed[i] & 0xffffffffu) * seed_scale : 0;
-    float ds = pair_dist(qx[u], qy[u], qz[u], txp[js], typ[js], tzp[js]);
-    if (!(ds <= 3.402823466e38f)) {  // inf/NaN: fall back to the reference's literal seed, element 0
-      js = 0;
-      ds = pair_dist(qx[u], qy[u], qz[u], txp[0], typ[0], tzp[0]);
-    }
-    bd[u] = ds;
-    bj[u] = js;
-    T[u] = filt_threshold(ds);
-    key0[u] = ((nn_key_t)__float_as_uint(ds) << 32) | (nn_key_t)(unsigned)js;
-  }
-
-  const int j0 = blockIdx.y * tiles_per_chunk * NN_TILE;
-  int j1 = j0 + tiles_per_chunk * NN_TILE;
-  if (j1 > nt_pad) j1 = nt_pad;
-
-  // two SGPR buffers (A, B) of NNF_G targets: the scalar loads of one group are in
-  // flight while the other is consumed.  The last prefetch reads NNF_G floats past
-  // the chunk; every cloud allocation carries that much slack.
+__device__ __forceinline__ void scan_range(const float* __restrict__ txp, const float* __restrict__ typ,
+                                           const float* __restrict__ tzp, int j0, int j1, const float (&qx)[Q],
+                                           const float (&qy)[Q], const float (&qz)[Q], float (&bd)[Q], int (&bj)[Q],
+                                           float (&T)[Q]) {
   float XA[NNF_G], YA[NNF_G], ZA[NNF_G], XB[NNF_G], YB[NNF_G], ZB[NNF_G];
 #pragma unroll
   for (int k = 0; k < NNF_G; ++k) {
@@ -271,6 +244,88 @@ __global__ __launch_bounds__(NN_THREADS) void nn_filtered_kernel(
     for (int u = 0; u < Q; ++u) hit |= (m[u] <= T[u]);
     if (__builtin_amdgcn_ballot_w64(hit) != 0) group_exact<Q>(qx, qy, qz, XB, YB, ZB, e, j + NNF_G, bd, bj, T);
   }
+}
+
+// Lower bound of the squared distance from the lane's queries to an axis-aligned
+// box; true if some query of this lane may still find a passing target inside.
+// lb (fp32) <= s_j (1 + 6*2^-24) for every target j in the box, and a target passes
+// the filter only if e_j <= T with e_j >= s_j (1 - 3*2^-24), so lb <= T (1 + 2^-19)
+// is a safe (never wrongly skipping) test.  Empty boxes (lo = +inf, hi = -inf) never pass.
+template <int Q>
+__device__ __forceinline__ bool box_may_hit(const float (&qx)[Q], const float (&qy)[Q], const float (&qz)[Q], float lox,
+                                            float loy, float loz, float hix, float hiy, float hiz,
+                                            const float (&T)[Q]) {
+  bool hit = false;
+#pragma unroll
+  for (int u = 0; u < Q; ++u) {
+    const float dx = __builtin_fmaxf(__builtin_fmaxf(lox - qx[u], qx[u] - hix), 0.f);
+    const float dy = __builtin_fmaxf(__builtin_fmaxf(loy - qy[u], qy[u] - hiy), 0.f);
+    const float dz = __builtin_fmaxf(__builtin_fmaxf(loz - qz[u], qz[u] - hiz), 0.f);
+    const float lb = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+    hit |= (lb <= T[u] * (1.0f + 0x1p-19f));
+  }
+  return hit;
+}
+
+// PRUNE = false: every target of the chunk is scanned (brute force).
+// PRUNE = true : 1024-target tiles and their 128-target sub-tiles whose bounding box
+//                is farther than every lane's threshold are skipped with one test;
+//                results are identical (the test never skips a possible hit).
+template <int Q, bool PRUNE>
+__global__ __launch_bounds__(NN_THREADS) void nn_filtered_kernel(
+    const float* __restrict__ qxp, const float* __restrict__ qyp, const float* __restrict__ qzp, int nq,
+    const float* __restrict__ txp, const float* __restrict__ typ, const float* __restrict__ tzp, int nt_pad,
+    int tiles_per_chunk, const nn_key_t* __restrict__ seed, int seed_scale, nn_key_t* __restrict__ best,
+    const float* __restrict__ tbox, int tbox_stride, const float* __restrict__ sbox, int sbox_stride) {
+  const int tid = threadIdx.x;
+  const int ibase = blockIdx.x * (NN_THREADS * Q) + tid;
+  float qx[Q], qy[Q], qz[Q], bd[Q], T[Q];
+  int bj[Q];
+  nn_key_t key0[Q];
+#pragma unroll
+  for (int u = 0; u < Q; ++u) {
+    const int i = ibase + u * NN_THREADS;
+    const bool live = i < nq;
+    qx[u] = live ? qxp[i] : 0.f;
+    qy[u] = live ? qyp[i] : 0.f;
+    qz[u] = live ? qzp[i] : 0.f;
+    int js = live ? (int)(unsigned)(seed[i] & 0xffffffffu) * seed_scale : 0;
+    float ds = pair_dist(qx[u], qy[u], qz[u], txp[js], typ[js], tzp[js]);
+    if (!(ds <= 3.402823466e38f)) {  // inf/NaN: fall back to the reference's literal seed, element 0
+      js = 0;
+      ds = pair_dist(qx[u], qy[u], qz[u], txp[0], typ[0], tzp[0]);
+    }
+    bd[u] = ds;
+    bj[u] = js;
+    T[u] = filt_threshold(ds);
+    key0[u] = ((nn_key_t)__float_as_uint(ds) << 32) | (nn_key_t)(unsigned)js;
+  }
+
+  const int ntiles = nt_pad / NN_TILE;
+  const int tile0 = blockIdx.y * tiles_per_chunk;
+  int tile1 = tile0 + tiles_per_chunk;
+  if (tile1 > ntiles) tile1 = ntiles;
+
+  if (!PRUNE) {
+    scan_range<Q>(txp, typ, tzp, tile0 * NN_TILE, tile1 * NN_TILE, qx, qy, qz, bd, bj, T);
+  } else {
+    for (int t = tile0; t < tile1; ++t) {
+      const bool th = box_may_hit<Q>(qx, qy, qz, tbox[t], tbox[tbox_stride + t], tbox[2 * tbox_stride + t],
+                                     tbox[3 * tbox_stride + t], tbox[4 * tbox_stride + t], tbox[5 * tbox_stride + t], T);
+      if (__builtin_amdgcn_ballot_w64(th) == 0) continue;
+#pragma unroll 1
+      for (int k = 0; k < NN_SUBS; ++k) {
+        const int sb = t * NN_SUBS + k;  // uniform: six scalar loads
+        const bool sh = box_may_hit<Q>(qx, qy, qz, sbox[sb], sbox[sbox_stride + sb], sbox[2 * sbox_stride + sb],
+                                       sbox[3 * sbox_stride + sb], sbox[4 * sbox_stride + sb],
+                                       sbox[5 * sbox_stride + sb], T);
+        if (__builtin_amdgcn_ballot_w64(sh) != 0) {
+          const int js = sb * NN_SUB;
+          scan_range<Q>(txp, typ, tzp, js, js + NN_SUB, qx, qy, qz, bd, bj, T);
+        }
+      }
+    }
+  }
 
 #pragma unroll
   for (int u = 0; u < Q; ++u) {
@@ -282,18 +337,76 @@ __global__ __launch_bounds__(NN_THREADS) void nn_filtered_kernel(
   }
 }
 
-void launch_nn_filtered(const NnArgs& a, const nn_key_t* seed, int seed_scale, int q_per_lane, hipStream_t s) {
+void launch_nn_filtered(const NnArgs& a, const nn_key_t* seed, int seed_scale, int q_per_lane, const NnBoxes* boxes,
+                        hipStream_t s) {
   const int ntiles = a.nt_pad / NN_TILE;
   const int nchunks = (ntiles + a.tiles_per_chunk - 1) / a.tiles_per_chunk;
-  if (q_per_lane == 2) {
-    dim3 grid((a.nq + 2 * NN_THREADS - 1) / (2 * NN_THREADS), nchunks);
-    hipLaunchKernelGGL(nn_filtered_kernel<2>, grid, dim3(NN_THREADS), 0, s, a.qx, a.qy, a.qz, a.nq, a.tx, a.ty, a.tz,
-                       a.nt_pad, a.tiles_per_chunk, seed, seed_scale, a.best);
+  const int q = q_per_lane == 2 ? 2 : 1;
+  dim3 grid((a.nq + q * NN_THREADS - 1) / (q * NN_THREADS), nchunks);
+#define ICPK_LAUNCH(Q, P)                                                                                           \
+  hipLaunchKernelGGL((nn_filtered_kernel<Q, P>), grid, dim3(NN_THREADS), 0, s, a.qx, a.qy, a.qz, a.nq, a.tx, a.ty,   \
+                     a.tz, a.nt_pad, a.tiles_per_chunk, seed, seed_scale, a.best, boxes ? boxes->tbox : nullptr,     \
+                     boxes ? boxes->tbox_stride : 0, boxes ? boxes->sbox : nullptr, boxes ? boxes->sbox_stride : 0)
+  if (boxes) {
+    if (q == 2) ICPK_LAUNCH(2, true); else ICPK_LAUNCH(1, true);
   } else {
-    dim3 grid((a.nq + NN_THREADS - 1) / NN_THREADS, nchunks);
-    hipLaunchKernelGGL(nn_filtered_kernel<1>, grid, dim3(NN_THREADS), 0, s, a.qx, a.qy, a.qz, a.nq, a.tx, a.ty, a.tz,
-                       a.nt_pad, a.tiles_per_chunk, seed, seed_scale, a.best);
+    if (q == 2) ICPK_LAUNCH(2, false); else ICPK_LAUNCH(1, false);
   }
+#undef ICPK_LAUNCH
+}
+
+// Bounding boxes of the target cloud: one 512-lane workgroup per 1024-point tile, one
+// wave per 128-point sub-tile (2 points per lane, wave64 min/max butterfly).  Padded
+// (+inf) slots are ignored; an all-padding sub-tile gets the empty box (+inf, -inf).
+__global__ __launch_bounds__(512) void tile_boxes_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                         const float* __restrict__ z, int n, float* __restrict__ tbox,
+                                                         int tbox_stride, float* __restrict__ sbox, int sbox_stride) {
+  __shared__ float wlo[3][NN_SUBS], whi[3][NN_SUBS];
+  const int t = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const float* p[3] = {x, y, z};
+  float lo[3], hi[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    lo[c] = __builtin_inff();
+    hi[c] = -__builtin_inff();
+#pragma unroll
+    for (int r = 0; r < NN_SUB / 64; ++r) {
+      const int j = t * NN_TILE + wave * NN_SUB + r * 64 + lane;
+      if (j < n) {
+        const float v = p[c][j];
+        lo[c] = __builtin_fminf(lo[c], v);
+        hi[c] = __builtin_fmaxf(hi[c], v);
+      }
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+      lo[c] = __builtin_fminf(lo[c], __shfl_xor(lo[c], m, 64));
+      hi[c] = __builtin_fmaxf(hi[c], __shfl_xor(hi[c], m, 64));
+    }
+    if (lane == 0) {
+      sbox[c * sbox_stride + t * NN_SUBS + wave] = lo[c];
+      sbox[(3 + c) * sbox_stride + t * NN_SUBS + wave] = hi[c];
+      wlo[c][wave] = lo[c];
+      whi[c][wave] = hi[c];
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const int c = threadIdx.x;
+    float l = wlo[c][0], h = whi[c][0];
+    for (int k = 1; k < NN_SUBS; ++k) {
+      l = __builtin_fminf(l, wlo[c][k]);
+      h = __builtin_fmaxf(h, whi[c][k]);
+    }
+    tbox[c * tbox_stride + t] = l;
+    tbox[(3 + c) * tbox_stride + t] = h;
+  }
+}
+
+void launch_tile_boxes(const float* x, const float* y, const float* z, int n, int ntiles, const NnBoxes& b,
+                       hipStream_t s) {
+  hipLaunchKernelGGL(tile_boxes_kernel, dim3(ntiles), dim3(512), 0, s, x, y, z, n, b.tbox, b.tbox_stride, b.sbox,
+                     b.sbox_stride);
 }
 
 // every `stride`-th target -> coarse cloud for the seeding pre-pass

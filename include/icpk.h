@@ -55,6 +55,8 @@ extern "C" {
 /* nearest-neighbour kernel selection */
 #define ICPK_NN_EXACT 0    /* literal double-precision distance per pair             */
 #define ICPK_NN_FILTERED 1 /* seeded fp32 filter + exact re-evaluation; same results */
+#define ICPK_NN_PRUNED 2   /* FILTERED + skipping of target tiles whose bounding box is out \
+                              of reach; same results; default                          */
 
 /* log keys mirrored from SLAM.hpp:4-13 for the optional callback */
 #define ICPK_LOG_NEAREST_NEIGHBOR 0

@@ -315,14 +315,20 @@ def test_backproject_bit_exact(ctx, oracle):
 
 
 # ------------------------------------------------- filtered NN (ICPK_NN_FILTERED) --
-def _check_nn_filtered(ctx, oracle, src, tgt, moves=2):
+def _check_nn_filtered(ctx, oracle, src, tgt, moves=2, modes=(binding.NN_FILTERED, binding.NN_PRUNED)):
     """First sweep (coarse-seeded) and re-sweeps after moving the source (seeded by
-    the previous matches) must equal the oracle bit for bit."""
+    the previous matches) must equal the oracle bit for bit, with and without
+    bounding-box pruning."""
+    for mode in modes:
+        _check_nn_filtered_mode(ctx, oracle, src, tgt, moves, mode)
+
+
+def _check_nn_filtered_mode(ctx, oracle, src, tgt, moves, mode):
     ctx.set_target(tgt)
     ctx.set_source(src)
     cur = src
     for it in range(moves + 1):
-        idx, dist = ctx.nn(binding.NN_FILTERED)
+        idx, dist = ctx.nn(mode)
         oidx, odist = oracle.nn_bruteforce(cur, tgt, threads=oracle.max_threads())
         assert np.array_equal(idx, oidx), f"sweep {it}"
         assert np.array_equal(dist.view(np.uint32), odist.view(np.uint32)), f"sweep {it}"
@@ -346,10 +352,11 @@ def test_nn_filtered_ties_collisions_duplicates(ctx, oracle):
     _check_nn_filtered(ctx, oracle, p["source"], p["target"])
     tgt2 = np.concatenate([p["target"], p["target"]], axis=1)  # exact twins 4800 later
     _check_nn_filtered(ctx, oracle, p["source"], tgt2)
-    ctx.set_target(tgt2)
-    ctx.set_source(p["source"])
-    idx, _ = ctx.nn(binding.NN_FILTERED)
-    assert (idx < 4800).all()
+    for mode in (binding.NN_FILTERED, binding.NN_PRUNED):
+        ctx.set_target(tgt2)
+        ctx.set_source(p["source"])
+        idx, _ = ctx.nn(mode)
+        assert (idx < 4800).all()
     # sqrt-collision class: indices 62 and 63 share the float distance, 62 must win
     q = np.zeros((3, 1), np.float32)
     k = np.arange(63, -1, -1).astype(np.float64)
@@ -357,10 +364,11 @@ def test_nn_filtered_ties_collisions_duplicates(ctx, oracle):
     tgt = np.stack([np.ones_like(ys), ys, np.zeros_like(ys)]).astype(np.float32)
     far = np.full((3, 3000), 50, np.float32)
     for t in (tgt, np.concatenate([tgt[:, :63], far, tgt[:, 63:]], axis=1)):
-        ctx.set_target(t)
-        ctx.set_source(q)
-        idx, dist = ctx.nn(binding.NN_FILTERED)
-        assert idx[0] == 62 and dist[0] == np.float32(1.0)
+        for mode in (binding.NN_FILTERED, binding.NN_PRUNED):
+            ctx.set_target(t)
+            ctx.set_source(q)
+            idx, dist = ctx.nn(mode)
+            assert idx[0] == 62 and dist[0] == np.float32(1.0)
     # query identical to a target (distance 0, threshold 0 + slack) and all-equal targets
     tgt = np.tile(np.array([[1.0], [2.0], [3.0]], np.float32), (1, 2000))
     src = np.array([[1.0, 1.5], [2.0, 2.0], [3.0, 3.0]], np.float32)
@@ -391,14 +399,17 @@ def test_nn_filtered_kinect_quarter_frame_and_exact_agree(ctx, oracle):
     ctx.set_source(p["source"])
     a = ctx.nn(binding.NN_EXACT)
     b = ctx.nn(binding.NN_FILTERED)  # seeded by the exact sweep's matches
+    c = ctx.nn(binding.NN_PRUNED)
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    assert np.array_equal(a[0], c[0]) and np.array_equal(a[1], c[1])
 
 
+@pytest.mark.parametrize("mode", [binding.NN_FILTERED, binding.NN_PRUNED])
 @pytest.mark.parametrize("solve", [binding.SOLVE_REFERENCE, binding.SOLVE_KABSCH])
-def test_align_filtered_matches_oracle(ctx, oracle, solve):
+def test_align_filtered_matches_oracle(ctx, oracle, solve, mode):
     p = synth.kinect_pair(rows=240, cols=320, seed=3)
     T, st, rc, o = _align_both(ctx, oracle, p["source"], p["target"], solve=solve, max_iterations=6,
-                               fixed_iterations=1, nn_mode=binding.NN_FILTERED)
+                               fixed_iterations=1, nn_mode=mode)
     assert st.iterations == o["iterations"] == 6
     assert np.array_equal(T, o["T"])  # bit-identical, not just within 1e-5
     idx, dist = ctx.get_associations()
@@ -422,6 +433,9 @@ def test_full_size_kinect_pair_properties(ctx):
     ctx.reset_source()  # drops the seeds: the filtered sweep starts from the coarse pre-pass
     i_f, d_f = ctx.nn(binding.NN_FILTERED)
     assert np.array_equal(ie, i_f) and np.array_equal(de.view(np.uint32), d_f.view(np.uint32))
+    ctx.reset_source()
+    i_p, d_p = ctx.nn(binding.NN_PRUNED)
+    assert np.array_equal(ie, i_p) and np.array_equal(de.view(np.uint32), d_p.view(np.uint32))
     assert np.array_equal(ctx.pair_distance(src, tgt[:, ie]).view(np.uint32), de.view(np.uint32))
     rng = np.random.default_rng(0)
     for q in rng.integers(0, src.shape[1], 40):
@@ -430,6 +444,8 @@ def test_full_size_kinect_pair_properties(ctx):
     T1, st1, _ = ctx.align(max_iterations=3, fixed_iterations=1, nn_mode=binding.NN_EXACT)
     T2, st2, _ = ctx.align(max_iterations=3, fixed_iterations=1, nn_mode=binding.NN_FILTERED)
     assert np.array_equal(T1, T2) and st1.final_pairs == st2.final_pairs and st1.final_mse == st2.final_mse
+    T3, st3, _ = ctx.align(max_iterations=3, fixed_iterations=1, nn_mode=binding.NN_PRUNED)
+    assert np.array_equal(T1, T3) and st1.final_pairs == st3.final_pairs and st1.final_mse == st3.final_mse
 
 
 def test_transform_target_commit_and_trace(ctx, oracle):
