@@ -15,7 +15,10 @@ LIB_PATH = os.path.join(HERE, "lib", "libicpk.so")
 OK = 0
 W_TOO_FEW_PAIRS = 1
 E_ARG, E_EMPTY_TARGET, E_HIP, E_NOT_SET, E_NO_DEVICE = -1, -2, -3, -4, -5
-SOLVE_REFERENCE, SOLVE_KABSCH = 0, 1
+SOLVE_REFERENCE, SOLVE_KABSCH, SOLVE_POINT_TO_PLANE = 0, 1, 2
+W_DEGENERATE = 2
+NORMALS_CROSS, NORMALS_REFERENCE = 0, 1
+NP2L = 28
 NN_EXACT, NN_FILTERED, NN_PRUNED = 0, 1, 2
 NSUM = 19
 
@@ -26,7 +29,8 @@ SYMBOLS = [
     "icpk_set_source_device", "icpk_reset_source", "icpk_commit_source", "icpk_get_source", "icpk_get_target", "icpk_source_size", "icpk_target_size",
     "icpk_nn", "icpk_reduce", "icpk_transform_source", "icpk_transform_target", "icpk_get_trace",
     "icpk_get_associations", "icpk_align",
-    "icpk_align_batch", "icpk_backproject", "icpk_pair_distance", "icpk_make_rotation_matrix",
+    "icpk_align_batch", "icpk_backproject", "icpk_backproject_with_normals", "icpk_set_target_normals",
+    "icpk_get_target_normals", "icpk_reduce_p2l", "icpk_solve_point_to_plane", "icpk_pair_distance", "icpk_make_rotation_matrix",
     "icpk_matrix_to_quaternion", "icpk_quaternion_to_euler", "icpk_solve_reference", "icpk_solve_kabsch",
 ]
 
@@ -120,6 +124,12 @@ def load():
     lib.icpk_backproject.argtypes = [C.c_void_p, C.POINTER(C.c_uint16), C.c_int32, C.c_int32, C.c_float, C.c_float,
                                      fp, C.c_int32]
     lib.icpk_pair_distance.argtypes = [C.c_void_p, fp, fp, fp, C.c_int32]
+    lib.icpk_backproject_with_normals.argtypes = [C.c_void_p, C.POINTER(C.c_uint16), C.c_int32, C.c_int32, C.c_float,
+                                                  C.c_float, fp, C.c_int32]
+    lib.icpk_set_target_normals.argtypes = [C.c_void_p, fp, fp, fp, C.c_int32]
+    lib.icpk_get_target_normals.argtypes = [C.c_void_p, fp, fp, fp]
+    lib.icpk_reduce_p2l.argtypes = [C.c_void_p, C.c_float, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    lib.icpk_solve_point_to_plane.argtypes = [C.POINTER(C.c_double)] * 3
     lib.icpk_default_params.argtypes = [C.POINTER(Params)]
     lib.icpk_default_params.restype = None
     lib.icpk_set_log_callback.argtypes = [C.c_void_p, LOG_FN, C.c_void_p]
@@ -184,6 +194,15 @@ def solve_reference(M):
     R = np.zeros(9, np.float32)
     load().icpk_solve_reference(_fp(M), _fp(R))
     return R.reshape(3, 3)
+
+
+def solve_point_to_plane(sums):
+    dp = C.POINTER(C.c_double)
+    sums = np.ascontiguousarray(sums, np.float64)
+    R = np.zeros(9)
+    t = np.zeros(3)
+    rc = load().icpk_solve_point_to_plane(sums.ctypes.data_as(dp), R.ctypes.data_as(dp), t.ctypes.data_as(dp))
+    return R.reshape(3, 3), t, rc
 
 
 def solve_kabsch(n, sa, sb, sab):
@@ -338,6 +357,30 @@ class Context:
         n = self._chk(self._lib.icpk_backproject(self._h, depth.ctypes.data_as(C.POINTER(C.c_uint16)), rows, cols,
                                                  fx, cx, None if off is None else _fp(off), which))
         return n
+
+    # -- point-to-plane extension ------------------------------------------------
+    def backproject_with_normals(self, depth, normals_mode=NORMALS_CROSS, fx=468.60, cx=318.27, offset=None):
+        depth = np.ascontiguousarray(depth, np.uint16)
+        rows, cols = depth.shape
+        off = None if offset is None else _f(offset)
+        return self._chk(self._lib.icpk_backproject_with_normals(
+            self._h, depth.ctypes.data_as(C.POINTER(C.c_uint16)), rows, cols, fx, cx,
+            None if off is None else _fp(off), normals_mode))
+
+    def set_target_normals(self, nrm):
+        x, y, z = (_f(nrm[k]) for k in range(3))
+        self._chk(self._lib.icpk_set_target_normals(self._h, _fp(x), _fp(y), _fp(z), x.size))
+
+    def get_target_normals(self):
+        out = np.empty((3, self.target_size), np.float32)
+        self._chk(self._lib.icpk_get_target_normals(self._h, _fp(out[0]), _fp(out[1]), _fp(out[2])))
+        return out
+
+    def reduce_p2l(self, max_dist=0.75):
+        sums = np.zeros(NP2L, np.float64)
+        cnt = C.c_int64(0)
+        self._chk(self._lib.icpk_reduce_p2l(self._h, max_dist, sums.ctypes.data_as(C.POINTER(C.c_double)), C.byref(cnt)))
+        return sums, cnt.value
 
     # -- loop ---------------------------------------------------------------------
     def align(self, params=None, **kw):

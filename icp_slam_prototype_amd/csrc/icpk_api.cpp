@@ -39,6 +39,8 @@ struct icpk_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   Cloud tgt, src0, src;
+  Cloud nrm;  // target normals (point-to-plane), same indexing as tgt
+  bool have_normals = false;
   Cloud dec;  // every NN_SEED_STRIDE-th target (seeding pre-pass of the filtered NN)
   bool have_tgt = false, have_src = false, have_assoc = false;
   bool have_dec = false;   // dec matches tgt
@@ -286,6 +288,17 @@ int enqueue_reduce(icpk_ctx* ctx, float max_dist) {
   return ICPK_OK;
 }
 
+// point-to-plane flavour of enqueue_reduce (K5)
+int enqueue_reduce_p2l(icpk_ctx* ctx, float max_dist) {
+  launch_p2l_reduce(ctx->best, ctx->src.x(), ctx->src.y(), ctx->src.z(), ctx->src.n, ctx->tgt.x(), ctx->tgt.y(),
+                    ctx->tgt.z(), ctx->nrm.x(), ctx->nrm.y(), ctx->nrm.z(), max_dist, ctx->idx, ctx->dist, ctx->partial,
+                    ctx->pcount, ctx->red_out, ctx->stream);
+  ICPK_HIP(ctx, hipGetLastError());
+  ICPK_HIP(ctx, hipMemcpyAsync(ctx->red_host, ctx->red_out, (NP2L + 1) * sizeof(double), hipMemcpyDeviceToHost,
+                               ctx->stream));
+  return ICPK_OK;
+}
+
 float mse_from(const double* sums, int64_t n) {
   // icp.cpp:622-638: (mean distance)^2, evaluated from the double sum
   if (n <= 0) return 0.f;
@@ -321,10 +334,10 @@ int icpk_create(icpk_ctx** out, int device_id) {
   icpk_ctx* ctx = new icpk_ctx();
   ctx->device = device_id;
   bool ok = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess;
-  ok = ok && hipMalloc((void**)&ctx->partial, (size_t)RED_MAX_BLOCKS * NSUM * sizeof(double)) == hipSuccess;
+  ok = ok && hipMalloc((void**)&ctx->partial, (size_t)RED_MAX_BLOCKS * NSUM_MAX * sizeof(double)) == hipSuccess;
   ok = ok && hipMalloc((void**)&ctx->pcount, (size_t)RED_MAX_BLOCKS * sizeof(int)) == hipSuccess;
-  ok = ok && hipMalloc((void**)&ctx->red_out, (NSUM + 1) * sizeof(double)) == hipSuccess;
-  ok = ok && hipHostMalloc((void**)&ctx->red_host, (NSUM + 1) * sizeof(double), hipHostMallocDefault) == hipSuccess;
+  ok = ok && hipMalloc((void**)&ctx->red_out, (NSUM_MAX + 1) * sizeof(double)) == hipSuccess;
+  ok = ok && hipHostMalloc((void**)&ctx->red_host, (NSUM_MAX + 1) * sizeof(double), hipHostMallocDefault) == hipSuccess;
   ok = ok && hipHostMalloc((void**)&ctx->bp_n_host, sizeof(int), hipHostMallocDefault) == hipSuccess;
   if (!ok) {
     icpk_destroy(ctx);
@@ -348,7 +361,7 @@ void icpk_destroy(icpk_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   for (hipEvent_t e : ctx->events) (void)hipEventDestroy(e);
-  void* dev[] = {ctx->boxes, ctx->dec.base, ctx->tgt.base, ctx->src0.base, ctx->src.base, ctx->best,      ctx->seed,     ctx->idx,
+  void* dev[] = {ctx->nrm.base, ctx->boxes, ctx->dec.base, ctx->tgt.base, ctx->src0.base, ctx->src.base, ctx->best,      ctx->seed,     ctx->idx,
                  ctx->dist,     ctx->partial,   ctx->pcount,   ctx->red_out,   ctx->depth_dev, ctx->bp_counts};
   for (void* p : dev)
     if (p) (void)hipFree(p);
@@ -380,6 +393,7 @@ static int set_target_impl(icpk_ctx* ctx, const float* x, const float* y, const 
   ctx->have_dec = false;
   ctx->have_boxes = false;
   ctx->have_seed = false;
+  ctx->have_normals = false;
   return ICPK_OK;
 }
 
@@ -540,6 +554,11 @@ int icpk_transform_target(icpk_ctx* ctx, const float R[9], const float t[3]) {
   launch_fill_f32(c.x() + c.n, padded - c.n, __builtin_inff(), ctx->stream);
   launch_fill_f32(c.y() + c.n, padded - c.n, __builtin_inff(), ctx->stream);
   launch_fill_f32(c.z() + c.n, padded - c.n, __builtin_inff(), ctx->stream);
+  if (ctx->have_normals) {  // normals rotate with the cloud (no translation)
+    Rt rn = rt;
+    rn.t[0] = rn.t[1] = rn.t[2] = 0.f;
+    launch_transform(ctx->nrm.x(), ctx->nrm.y(), ctx->nrm.z(), c.n, rn, ctx->stream);
+  }
   ICPK_HIP(ctx, hipGetLastError());
   ctx->have_assoc = false;
   ctx->have_dec = false;
@@ -565,8 +584,10 @@ int icpk_align(icpk_ctx* ctx, const icpk_params* p, float T_out[16], icpk_stats*
     for (int k = 0; k < 16; ++k) T_out[k] = (k % 5 == 0) ? 1.f : 0.f;  // identity on failure
   if (stats) std::memset(stats, 0, sizeof(*stats));
   if (!ctx || !p || !T_out) return ICPK_E_ARG;
-  if (p->max_iterations < 0 || (p->solve != ICPK_SOLVE_REFERENCE && p->solve != ICPK_SOLVE_KABSCH))
+  if (p->max_iterations < 0 || p->solve < ICPK_SOLVE_REFERENCE || p->solve > ICPK_SOLVE_POINT_TO_PLANE)
     return fail(ctx, ICPK_E_ARG, "bad params");
+  if (p->solve == ICPK_SOLVE_POINT_TO_PLANE && ctx && !ctx->have_normals)
+    return fail(ctx, ICPK_E_NOT_SET, "point-to-plane needs target normals");
   int rc = check_ready(ctx);
   if (rc) {
     if (stats) stats->status = rc;
@@ -590,7 +611,9 @@ int icpk_align(icpk_ctx* ctx, const icpk_params* p, float T_out[16], icpk_stats*
     return ICPK_OK;
   };
 
-  double sums[NSUM];
+  const bool p2l = p->solve == ICPK_SOLVE_POINT_TO_PLANE;
+  const int nsum = p2l ? NP2L : NSUM;
+  double sums[NSUM_MAX];
   int64_t npairs = 0;
   float mse = 0.f;
   int sweeps = 0;
@@ -602,20 +625,25 @@ int icpk_align(icpk_ctx* ctx, const icpk_params* p, float T_out[16], icpk_stats*
     r = stamp(&ev_red);  // end of NN == start of reduce
     if (r) return r;
     if (ctx->src.n > 0) {
-      r = enqueue_reduce(ctx, p->max_nn_dist);
+      r = p2l ? enqueue_reduce_p2l(ctx, p->max_nn_dist) : enqueue_reduce(ctx, p->max_nn_dist);
       if (r) return r;
     }
     r = stamp(nullptr);  // end of reduce
     if (r) return r;
     ICPK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->src.n > 0) {
-      std::memcpy(sums, ctx->red_host, sizeof(sums));
-      std::memcpy(&npairs, ctx->red_host + NSUM, sizeof(int64_t));
+      std::memcpy(sums, ctx->red_host, nsum * sizeof(double));
+      std::memcpy(&npairs, ctx->red_host + nsum, sizeof(int64_t));
     } else {
       std::memset(sums, 0, sizeof(sums));
       npairs = 0;
     }
-    mse = mse_from(sums, npairs);
+    if (p2l) {  // distance sum sits in the last slot
+      const float m = npairs > 0 ? (float)(sums[27] / (double)npairs) : 0.f;
+      mse = (float)((double)m * (double)m);
+    } else {
+      mse = mse_from(sums, npairs);
+    }
     ++sweeps;
     log_delta(ctx, ICPK_LOG_NEAREST_NEIGHBOR, (int)npairs);  // icp.cpp:561
     log_delta(ctx, ICPK_LOG_MSE, (int)npairs);               // icp.cpp:635
@@ -674,6 +702,28 @@ int icpk_align(icpk_ctx* ctx, const icpk_params* p, float T_out[16], icpk_stats*
       if (rc) return rc;
       ctx->trace_R.insert(ctx->trace_R.end(), R, R + 9);
       ctx->trace_t.insert(ctx->trace_t.end(), offset, offset + 3);
+    } else if (p2l) {
+      double Rd[9], td[3];
+      if (!solve_p2l(sums, Rd, td)) {
+        status = ICPK_W_DEGENERATE;
+        break;
+      }
+      log_delta(ctx, ICPK_LOG_SVD, 0);
+      float Rf[9], tf[3];
+      for (int k = 0; k < 9; ++k) Rf[k] = (float)Rd[k];
+      for (int k = 0; k < 3; ++k) tf[k] = (float)td[k];
+      rc = apply(Rf, tf);
+      if (rc) return rc;
+      ctx->trace_R.insert(ctx->trace_R.end(), Rf, Rf + 9);
+      ctx->trace_t.insert(ctx->trace_t.end(), tf, tf + 3);
+      double Tn[12];
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 4; ++c) {
+          double s = 0;
+          for (int k = 0; k < 3; ++k) s += (double)Rf[3 * r + k] * Tk[4 * k + c];
+          Tn[4 * r + c] = s + (c == 3 ? (double)tf[r] : 0.0);
+        }
+      std::memcpy(Tk, Tn, sizeof(Tk));
     } else {
       double sa[3], sb[3], sab[9], Rd[9], td[3];
       for (int k = 0; k < 3; ++k) {
@@ -760,9 +810,10 @@ int icpk_align_batch(icpk_ctx* ctx, int32_t n_pairs, const icpk_pair* pairs, con
   return worst;
 }
 
-int icpk_backproject(icpk_ctx* ctx, const uint16_t* depth, int32_t rows, int32_t cols, float fx, float cx,
-                     const float offset[3], int32_t which) {
-  if (!ctx || !depth || rows <= 0 || cols <= 0 || (which != 0 && which != 1) || (int64_t)rows * cols > (1 << 28))
+static int backproject_impl(icpk_ctx* ctx, const uint16_t* depth, int32_t rows, int32_t cols, float fx, float cx,
+                            const float offset[3], int32_t which, int normals_mode /* <0: none */) {
+  if (!ctx || !depth || rows <= 0 || cols <= 0 || (which != 0 && which != 1) || (int64_t)rows * cols > (1 << 28) ||
+      normals_mode > ICPK_NORMALS_REFERENCE)
     return ICPK_E_ARG;
   ICPK_HIP(ctx, hipSetDevice(ctx->device));
   const int npix = rows * cols;
@@ -787,8 +838,16 @@ int icpk_backproject(icpk_ctx* ctx, const uint16_t* depth, int32_t rows, int32_t
   ICPK_HIP(ctx, hipMemcpyAsync(ctx->depth_dev, depth, (size_t)npix * sizeof(uint16_t), hipMemcpyHostToDevice, ctx->stream));
   const float ox = offset ? offset[0] : 0.f, oy = offset ? offset[1] : 0.f, oz = offset ? offset[2] : 0.f;
   // the total lands in bp_counts[nblocks + 1] (device) and is read back pinned
-  launch_backproject(ctx->depth_dev, rows, cols, fx, cx, ox, oy, oz, c.x(), c.y(), c.z(), ctx->bp_counts,
-                     ctx->bp_counts + nblocks + 1, ctx->stream);
+  float *nxp = nullptr, *nyp = nullptr, *nzp = nullptr;
+  if (normals_mode >= 0) {
+    rc = ensure_cloud(ctx, ctx->nrm, npix);
+    if (rc) return rc;
+    nxp = ctx->nrm.x();
+    nyp = ctx->nrm.y();
+    nzp = ctx->nrm.z();
+  }
+  launch_backproject(ctx->depth_dev, rows, cols, fx, cx, ox, oy, oz, c.x(), c.y(), c.z(), nxp, nyp, nzp,
+                     normals_mode < 0 ? 0 : normals_mode, ctx->bp_counts, ctx->bp_counts + nblocks + 1, ctx->stream);
   ICPK_HIP(ctx, hipGetLastError());
   ICPK_HIP(ctx, hipMemcpyAsync(ctx->bp_n_host, ctx->bp_counts + nblocks + 1, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   ICPK_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -802,7 +861,11 @@ int icpk_backproject(icpk_ctx* ctx, const uint16_t* depth, int32_t rows, int32_t
   ICPK_HIP(ctx, hipGetLastError());
   ctx->have_assoc = false;
   ctx->have_seed = false;
-  if (which == 1) ctx->have_dec = ctx->have_boxes = false;
+  if (which == 1) {
+    ctx->have_dec = ctx->have_boxes = false;
+    ctx->have_normals = normals_mode >= 0;
+    if (ctx->have_normals) ctx->nrm.n = n;
+  }
   if (which == 0) {
     ctx->have_src = true;
     rc = copy_src0_to_src(ctx);
@@ -812,6 +875,64 @@ int icpk_backproject(icpk_ctx* ctx, const uint16_t* depth, int32_t rows, int32_t
   }
   ICPK_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return n;
+}
+
+int icpk_backproject(icpk_ctx* ctx, const uint16_t* depth, int32_t rows, int32_t cols, float fx, float cx,
+                     const float offset[3], int32_t which) {
+  return backproject_impl(ctx, depth, rows, cols, fx, cx, offset, which, -1);
+}
+
+int icpk_backproject_with_normals(icpk_ctx* ctx, const uint16_t* depth, int32_t rows, int32_t cols, float fx, float cx,
+                                  const float offset[3], int32_t normals_mode) {
+  if (normals_mode < 0) return ICPK_E_ARG;
+  return backproject_impl(ctx, depth, rows, cols, fx, cx, offset, 1, normals_mode);
+}
+
+int icpk_set_target_normals(icpk_ctx* ctx, const float* nx, const float* ny, const float* nz, int32_t n) {
+  if (!ctx) return ICPK_E_ARG;
+  if (!ctx->have_tgt) return fail(ctx, ICPK_E_NOT_SET, "target cloud not set");
+  if (n != ctx->tgt.n) return fail(ctx, ICPK_E_ARG, "normal count differs from the target size");
+  ICPK_HIP(ctx, hipSetDevice(ctx->device));
+  int rc = upload_cloud(ctx, ctx->nrm, nx, ny, nz, n, 0.f, hipMemcpyHostToDevice);
+  if (rc) return rc;
+  ctx->have_normals = true;
+  return ICPK_OK;
+}
+
+int icpk_get_target_normals(icpk_ctx* ctx, float* nx, float* ny, float* nz) {
+  if (!ctx || !nx || !ny || !nz) return ICPK_E_ARG;
+  if (!ctx->have_normals) return fail(ctx, ICPK_E_NOT_SET, "no target normals");
+  ICPK_HIP(ctx, hipSetDevice(ctx->device));
+  const size_t b = (size_t)ctx->tgt.n * sizeof(float);
+  if (b) {
+    ICPK_HIP(ctx, hipMemcpyAsync(nx, ctx->nrm.x(), b, hipMemcpyDeviceToHost, ctx->stream));
+    ICPK_HIP(ctx, hipMemcpyAsync(ny, ctx->nrm.y(), b, hipMemcpyDeviceToHost, ctx->stream));
+    ICPK_HIP(ctx, hipMemcpyAsync(nz, ctx->nrm.z(), b, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  ICPK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return ICPK_OK;
+}
+
+int icpk_reduce_p2l(icpk_ctx* ctx, float max_dist, double* sums, int64_t* count) {
+  if (!ctx || !sums) return ICPK_E_ARG;
+  if (!ctx->have_assoc) return fail(ctx, ICPK_E_NOT_SET, "no nearest-neighbour sweep has run");
+  if (!ctx->have_normals) return fail(ctx, ICPK_E_NOT_SET, "no target normals");
+  ICPK_HIP(ctx, hipSetDevice(ctx->device));
+  if (ctx->src.n == 0) {
+    std::memset(sums, 0, NP2L * sizeof(double));
+    if (count) *count = 0;
+    return ICPK_OK;
+  }
+  int rc = enqueue_reduce_p2l(ctx, max_dist);
+  if (rc) return rc;
+  ICPK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  std::memcpy(sums, ctx->red_host, NP2L * sizeof(double));
+  if (count) std::memcpy(count, ctx->red_host + NP2L, sizeof(int64_t));
+  return ICPK_OK;
+}
+
+int icpk_solve_point_to_plane(const double sums[28], double R[9], double t[3]) {
+  return solve_p2l(sums, R, t) ? ICPK_OK : ICPK_W_DEGENERATE;
 }
 
 /* test hook: icp.cpp:606-620 on n pairs; a and b are host xyz-SoA [3][n] */

@@ -39,6 +39,8 @@ struct Rt {
 };
 
 constexpr int NSUM = 19;
+constexpr int NP2L = 28;      // point-to-plane: 21 + 6 + 1
+constexpr int NSUM_MAX = 28;
 constexpr int RED_THREADS = 256;
 constexpr int RED_MAX_BLOCKS = 256;
 
@@ -73,11 +75,16 @@ constexpr int NN_SEED_STRIDE = 16;  // decimation of the target for the seeding 
 void launch_pair_distance(const float* a, const float* b, float* out, int n, hipStream_t s);
 
 // kernels_reduce.hip
-// partial: [RED_MAX_BLOCKS][NSUM] doubles, pcount: [RED_MAX_BLOCKS] ints,
-// out: NSUM doubles followed by one int64 count (20 x 8 bytes).
+// partial: [RED_MAX_BLOCKS][NSUM_MAX] doubles, pcount: [RED_MAX_BLOCKS] ints,
+// out: nsum doubles followed by one int64 count ((NSUM_MAX + 1) x 8 bytes).
 void launch_assoc_reduce(const nn_key_t* best, const float* ax, const float* ay, const float* az, int nq,
                          const float* tx, const float* ty, const float* tz, float max_dist, int32_t* idx_out,
                          float* dist_out, double* partial, int* pcount, double* out, hipStream_t s);
+
+void launch_p2l_reduce(const nn_key_t* best, const float* ax, const float* ay, const float* az, int nq, const float* tx,
+                       const float* ty, const float* tz, const float* nx, const float* ny, const float* nz,
+                       float max_dist, int32_t* idx_out, float* dist_out, double* partial, int* pcount, double* out,
+                       hipStream_t s);
 
 // kernels_transform.hip
 void launch_transform(float* x, float* y, float* z, int n, const Rt& rt, hipStream_t s);
@@ -86,7 +93,9 @@ void launch_fill_f32(float* p, int n, float v, hipStream_t s);
 // kernels_backproject.hip
 // counts: [ceil(npix/1024)+1] ints scratch.  Returns nothing; *n_out (device)
 // receives the number of points.
+// nx == nullptr: no normals
 void launch_backproject(const uint16_t* depth, int rows, int cols, float fx, float cx, float ox, float oy, float oz,
-                        float* x, float* y, float* z, int* block_counts, int* n_out, hipStream_t s);
+                        float* x, float* y, float* z, float* nx, float* ny, float* nz, int normals_mode,
+                        int* block_counts, int* n_out, hipStream_t s);
 
 }  // namespace icpk

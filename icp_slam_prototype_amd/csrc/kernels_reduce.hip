@@ -75,23 +75,99 @@ __global__ __launch_bounds__(RED_THREADS) void assoc_reduce_kernel(
 // first staged in LDS with coalesced loads so the serial adds do not each wait
 // on a global-memory round trip
 __global__ __launch_bounds__(256) void reduce_final_kernel(const double* __restrict__ partial,
-                                                           const int* __restrict__ pcount, int nblocks,
+                                                           const int* __restrict__ pcount, int nblocks, int nsum,
                                                            double* __restrict__ out) {
-  __shared__ double sp[RED_MAX_BLOCKS * NSUM];
+  __shared__ double sp[RED_MAX_BLOCKS * NSUM_MAX];
   __shared__ int sc[RED_MAX_BLOCKS];
   const int tid = threadIdx.x;
-  for (int k = tid; k < nblocks * NSUM; k += 256) sp[k] = partial[k];
+  for (int k = tid; k < nblocks * nsum; k += 256) sp[k] = partial[k];
   for (int k = tid; k < nblocks; k += 256) sc[k] = pcount[k];
   __syncthreads();
-  if (tid < NSUM) {
+  if (tid < nsum) {
     double t = 0.0;
-    for (int b = 0; b < nblocks; ++b) t += sp[b * NSUM + tid];
+    for (int b = 0; b < nblocks; ++b) t += sp[b * nsum + tid];
     out[tid] = t;
-  } else if (tid == NSUM) {
+  } else if (tid == nsum) {
     long long c = 0;
     for (int b = 0; b < nblocks; ++b) c += sc[b];
-    reinterpret_cast<long long*>(out)[NSUM] = c;
+    reinterpret_cast<long long*>(out)[nsum] = c;
   }
+}
+
+// K5: normal equations of the linearised point-to-plane step (extension; the
+// reference only plans it, TODO:9).  Per accepted pair (dist < max_dist and a
+// non-zero target normal n): J = [p x n ; n], r = (p - q).n; 21 upper-triangle
+// entries of J J^T, 6 of J r, 1 distance sum -- same canonical tree as K2.
+__global__ __launch_bounds__(RED_THREADS) void p2l_reduce_kernel(
+    const nn_key_t* __restrict__ best, const float* __restrict__ ax, const float* __restrict__ ay,
+    const float* __restrict__ az, int nq, const float* __restrict__ tx, const float* __restrict__ ty,
+    const float* __restrict__ tz, const float* __restrict__ nxp, const float* __restrict__ nyp,
+    const float* __restrict__ nzp, float max_dist, int32_t* __restrict__ idx_out, float* __restrict__ dist_out,
+    double* __restrict__ partial, int* __restrict__ pcount) {
+  const int tid = threadIdx.x;
+  const int P = gridDim.x * RED_THREADS;
+  double v[NP2L];
+#pragma unroll
+  for (int s = 0; s < NP2L; ++s) v[s] = 0.0;
+  int cnt = 0;
+  for (int i = blockIdx.x * RED_THREADS + tid; i < nq; i += P) {
+    const nn_key_t key = best[i];
+    const float d = __uint_as_float((unsigned)(key >> 32));
+    const int j = (int)(unsigned)(key & 0xffffffffu);
+    idx_out[i] = j;
+    dist_out[i] = d;
+    if (d < max_dist) {
+      const double n0 = nxp[j], n1 = nyp[j], n2 = nzp[j];
+      if (!(n0 == 0.0 && n1 == 0.0 && n2 == 0.0)) {
+        const double p0 = ax[i], p1 = ay[i], p2 = az[i];
+        const double q0 = tx[j], q1 = ty[j], q2 = tz[j];
+        double J[6];
+        J[0] = p1 * n2 - p2 * n1;
+        J[1] = p2 * n0 - p0 * n2;
+        J[2] = p0 * n1 - p1 * n0;
+        J[3] = n0;
+        J[4] = n1;
+        J[5] = n2;
+        const double r = ((p0 - q0) * n0 + (p1 - q1) * n1) + (p2 - q2) * n2;
+        int k = 0;
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+          for (int b = a; b < 6; ++b) v[k++] += J[a] * J[b];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) v[21 + a] += J[a] * r;
+        v[27] += (double)d;
+        ++cnt;
+      }
+    }
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+#pragma unroll
+    for (int s = 0; s < NP2L; ++s) v[s] += __shfl_xor(v[s], m, 64);
+    cnt += __shfl_xor(cnt, m, 64);
+  }
+  __shared__ double ws[RED_THREADS / 64][NP2L];
+  __shared__ int wc[RED_THREADS / 64];
+  const int wave = tid >> 6, lane = tid & 63;
+  if (lane == 0) {
+#pragma unroll
+    for (int s = 0; s < NP2L; ++s) ws[wave][s] = v[s];
+    wc[wave] = cnt;
+  }
+  __syncthreads();
+  if (tid < NP2L) partial[blockIdx.x * NP2L + tid] = ((ws[0][tid] + ws[1][tid]) + ws[2][tid]) + ws[3][tid];
+  if (tid == NP2L) pcount[blockIdx.x] = wc[0] + wc[1] + wc[2] + wc[3];
+}
+
+void launch_p2l_reduce(const nn_key_t* best, const float* ax, const float* ay, const float* az, int nq, const float* tx,
+                       const float* ty, const float* tz, const float* nx, const float* ny, const float* nz,
+                       float max_dist, int32_t* idx_out, float* dist_out, double* partial, int* pcount, double* out,
+                       hipStream_t s) {
+  const int B = red_blocks(nq);
+  hipLaunchKernelGGL(p2l_reduce_kernel, dim3(B), dim3(RED_THREADS), 0, s, best, ax, ay, az, nq, tx, ty, tz, nx, ny, nz,
+                     max_dist, idx_out, dist_out, partial, pcount);
+  hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(256), 0, s, partial, pcount, B, NP2L, out);
 }
 
 void launch_assoc_reduce(const nn_key_t* best, const float* ax, const float* ay, const float* az, int nq,
@@ -100,7 +176,7 @@ void launch_assoc_reduce(const nn_key_t* best, const float* ax, const float* ay,
   const int B = red_blocks(nq);
   hipLaunchKernelGGL(assoc_reduce_kernel, dim3(B), dim3(RED_THREADS), 0, s, best, ax, ay, az, nq, tx, ty, tz,
                      max_dist, idx_out, dist_out, partial, pcount);
-  hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(256), 0, s, partial, pcount, B, out);
+  hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(256), 0, s, partial, pcount, B, NSUM, out);
 }
 
 }  // namespace icpk

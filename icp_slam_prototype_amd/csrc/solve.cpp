@@ -169,6 +169,56 @@ void solve_kabsch(int64_t n, const double sa[3], const double sb[3], const doubl
   for (int r = 0; r < 3; ++r) t[r] = -(R[3 * r] * ca[0] + R[3 * r + 1] * ca[1] + R[3 * r + 2] * ca[2]) + cb[r];  // :36
 }
 
+bool solve_p2l(const double sums[28], double R[9], double t[3]) {
+  double A[6][6], L[6][6] = {}, y[6], x[6];
+  for (int a = 0, k = 0; a < 6; ++a)
+    for (int b = a; b < 6; ++b, ++k) A[a][b] = A[b][a] = sums[k];
+  double dmax = 0.0;
+  for (int a = 0; a < 6; ++a) dmax = A[a][a] > dmax ? A[a][a] : dmax;
+  for (int i = 0; i < 6; ++i)
+    for (int j = 0; j <= i; ++j) {
+      double s = A[i][j];
+      for (int m = 0; m < j; ++m) s -= L[i][m] * L[j][m];
+      if (i == j) {
+        if (!(s > 1e-12 * dmax)) return false;  // not positive definite: degenerate geometry
+        L[i][i] = std::sqrt(s);
+      } else {
+        L[i][j] = s / L[j][j];
+      }
+    }
+  for (int i = 0; i < 6; ++i) {  // L y = -b
+    double s = -sums[21 + i];
+    for (int m = 0; m < i; ++m) s -= L[i][m] * y[m];
+    y[i] = s / L[i][i];
+  }
+  for (int i = 5; i >= 0; --i) {  // L^T x = y
+    double s = y[i];
+    for (int m = i + 1; m < 6; ++m) s -= L[m][i] * x[m];
+    x[i] = s / L[i][i];
+  }
+  // Rodrigues: R = I + A1 K + B1 K^2, K = [alpha]x
+  const double a0 = x[0], a1 = x[1], a2 = x[2];
+  const double th2 = (a0 * a0 + a1 * a1) + a2 * a2, th = std::sqrt(th2);
+  double A1, B1;
+  if (th < 1e-9) {
+    A1 = 1.0 - th2 / 6.0;
+    B1 = 0.5 - th2 / 24.0;
+  } else {
+    A1 = std::sin(th) / th;
+    B1 = (1.0 - std::cos(th)) / th2;
+  }
+  const double K[9] = {0, -a2, a1, a2, 0, -a0, -a1, a0, 0};
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) {
+      const double k2 = (K[3 * r] * K[c] + K[3 * r + 1] * K[3 + c]) + K[3 * r + 2] * K[6 + c];
+      R[3 * r + c] = (r == c ? 1.0 : 0.0) + (A1 * K[3 * r + c] + B1 * k2);
+    }
+  t[0] = x[3];
+  t[1] = x[4];
+  t[2] = x[5];
+  return true;
+}
+
 void make_rotation_matrix(float x, float y, float z, float out[9]) {
   const float PI = 3.14159265358979f;  // icp.hpp:4
   const double rx = x * PI / 180, ry = y * PI / 180, rz = z * PI / 180;

@@ -21,6 +21,10 @@ void mul3f(const float A[9], const float B[9], float C[9]);
 // rigid_transform_3D.py:9-40 from raw sums
 void solve_kabsch(int64_t n, const double sa[3], const double sb[3], const double sab[9], double R[9], double t[3]);
 
+// point-to-plane step (extension): sums = 21 upper-triangle J J^T, 6 J r, (1 unused);
+// solves A x = -b by Cholesky, x = (alpha, t), R = exp([alpha]x).  false if A is not SPD.
+bool solve_p2l(const double sums[28], double R[9], double t[3]);
+
 // icp.cpp:640-653, quaternion.cpp:23-79, SLAM.cpp:613-636
 void make_rotation_matrix(float x, float y, float z, float out[9]);
 void matrix_to_quaternion(const float m[9], float q[4]);

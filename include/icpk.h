@@ -29,6 +29,8 @@ extern "C" {
 
 /* ---- status codes -------------------------------------------------------- */
 #define ICPK_OK 0
+#define ICPK_W_DEGENERATE 2       /* point-to-plane normal equations not positive definite:  \
+                                    iteration stopped, transform so far returned            */
 #define ICPK_W_TOO_FEW_PAIRS 1   /* < min_pairs associations: fell back to the  \
                                     caller's last motion (icp.cpp:163-182)      */
 #define ICPK_E_ARG (-1)          /* null pointer / negative size / bad enum     */
@@ -51,6 +53,8 @@ extern "C" {
 #define ICPK_SOLVE_REFERENCE 0 /* bug-for-bug icp.cpp:199-246 (un-centred moment,    \
                                   R = V U^T, column-2 flip, mean-difference offset)  */
 #define ICPK_SOLVE_KABSCH 1    /* centred Kabsch, rigid_transform_3D.py:9-40         */
+#define ICPK_SOLVE_POINT_TO_PLANE 2 /* linearised point-to-plane (extension: TODO:9 of the \
+                                       reference only plans it); needs target normals     */
 
 /* nearest-neighbour kernel selection */
 #define ICPK_NN_EXACT 0    /* literal double-precision distance per pair             */
@@ -72,6 +76,8 @@ extern "C" {
  * order. */
 #define ICPK_RED_THREADS 256
 #define ICPK_RED_MAX_BLOCKS 256
+#define ICPK_NP2L 28 /* point-to-plane sums: [0..20] upper triangle of J J^T (row-major),  \
+                        [21..26] J r, [27] sum dist; J = [p x n ; n], r = (p - q).n      */
 #define ICPK_NSUM 19 /* [0..8] M[r][c]=sum b_r a_c, [9..11] sum (float)(a-b), \
                         [12] sum dist, [13..15] sum a, [16..18] sum b          */
 
@@ -197,6 +203,22 @@ int icpk_align_batch(icpk_ctx *ctx, int32_t n_pairs, const icpk_pair *pairs,
  * Returns the number of points (>= 0) or a negative status. */
 int icpk_backproject(icpk_ctx *ctx, const uint16_t *depth, int32_t rows, int32_t cols,
                      float fx, float cx, const float offset[3], int32_t which);
+
+/* ---- point-to-plane extension (BASELINE config 3; not in the reference) ---- */
+#define ICPK_NORMALS_CROSS 0     /* normalised cross product of back-projected central differences */
+#define ICPK_NORMALS_REFERENCE 1 /* SLAM.cpp:421-425 getNormalMap formula, interior pixels          */
+/* target cloud AND one normal per point from a depth image (as icpk_backproject
+ * with which = 1); pixels without a normal get (0,0,0) and never pair. */
+int icpk_backproject_with_normals(icpk_ctx *ctx, const uint16_t *depth, int32_t rows, int32_t cols,
+                                  float fx, float cx, const float offset[3], int32_t normals_mode);
+/* normals for the current target cloud from host arrays (n must equal the target size) */
+int icpk_set_target_normals(icpk_ctx *ctx, const float *nx, const float *ny, const float *nz, int32_t n);
+int icpk_get_target_normals(icpk_ctx *ctx, float *nx, float *ny, float *nz);
+/* K5: the 28 canonical sums of the linearised point-to-plane step over the
+ * associations of the last sweep (see ICPK_NP2L) */
+int icpk_reduce_p2l(icpk_ctx *ctx, float max_dist, double *sums, int64_t *count);
+/* host solve of the step: 0 ok, ICPK_W_DEGENERATE if not positive definite */
+int icpk_solve_point_to_plane(const double sums[28], double R[9], double t[3]);
 
 /* ---- test hook ------------------------------------------------------------ */
 /* icp.cpp:606-620 distance(color_point_t, color_point_t) evaluated on the

@@ -621,6 +621,196 @@ ORC_API void orc_depth_range_filter(uint16_t *depth, int n, int max_d, int min_d
 }
 
 /* ======================================================================== */
+/* Point-to-plane extension (BASELINE config 3).  NOT in the reference        */
+/* (TODO:9 "Look into Point to Plane"); PARITY UNPINNED by construction: this */
+/* float64 restatement is the only oracle.  The one reference artefact is the */
+/* dead getNormalMap (SLAM.cpp:412-430), restated as normals mode 1.          */
+/* ======================================================================== */
+#define ORC_NP2L 28 /* 21 upper-triangle J J^T + 6 J r + 1 sum dist */
+
+/* Back-projection (as orc_backproject, no keep mask) plus one normal per      */
+/* valid pixel, compacted in the same order.                                   */
+/* mode 0: n = normalize((P(r,c+1)-P(r,c-1)) x (P(r+1,c)-P(r-1,c))), float     */
+/*         arithmetic, all four neighbours must be valid, else n = 0;          */
+/* mode 1: SLAM.cpp:421-425 literally: central differences of the RAW depth    */
+/*         (as float) along rows ("x") and columns ("y"), d = (-dzdx,-dzdy,1), */
+/*         cv::normalize (norm in double, components scaled by 1/norm);        */
+/*         interior pixels only (the reference reads out of bounds at the      */
+/*         last row/column), border n = 0.                                     */
+ORC_API int orc_backproject_normals(const uint16_t *depth, int rows, int cols, float fx,
+                                    float cx, int mode, float *x, float *y, float *z,
+                                    float *nx, float *ny, float *nz) {
+#define ORC_D(r, c) depth[(size_t)(r) * cols + (c)]
+  int n = 0;
+  for (int r = 0; r < rows; r++)
+    for (int c = 0; c < cols; c++) {
+      uint16_t d = ORC_D(r, c);
+      if (d == 0) continue;
+      float pz = ((float)d) / 5000.0f;
+      x[n] = (c - cx) * pz / fx;
+      y[n] = (r - cx) * pz / fx;
+      z[n] = pz;
+      float ox = 0.f, oy = 0.f, oz = 0.f;
+      int interior = (r > 0 && r < rows - 1 && c > 0 && c < cols - 1);
+      if (mode == 0) {
+        if (interior && ORC_D(r, c + 1) && ORC_D(r, c - 1) && ORC_D(r + 1, c) && ORC_D(r - 1, c)) {
+          float P[4][3];
+          const int rr[4] = {r, r, r + 1, r - 1}, cc[4] = {c + 1, c - 1, c, c};
+          for (int k = 0; k < 4; k++) {
+            float qz = ((float)ORC_D(rr[k], cc[k])) / 5000.0f;
+            P[k][0] = (cc[k] - cx) * qz / fx;
+            P[k][1] = (rr[k] - cx) * qz / fx;
+            P[k][2] = qz;
+          }
+          float ax = P[0][0] - P[1][0], ay = P[0][1] - P[1][1], az = P[0][2] - P[1][2];
+          float bx = P[2][0] - P[3][0], by = P[2][1] - P[3][1], bz = P[2][2] - P[3][2];
+          float m0 = ay * bz, m1 = az * by, m2 = az * bx, m3 = ax * bz, m4 = ax * by, m5 = ay * bx;
+          float vx = m0 - m1, vy = m2 - m3, vz = m4 - m5;
+          float s0 = vx * vx, s1 = vy * vy, s2 = vz * vz;
+          float l2 = (s0 + s1) + s2;
+          float l = sqrtf(l2);
+          if (l > 0.f) {
+            ox = vx / l;
+            oy = vy / l;
+            oz = vz / l;
+          }
+        }
+      } else if (interior) {
+        float dzdx = ((float)ORC_D(r + 1, c) - (float)ORC_D(r - 1, c)) / 2.0f; /* SLAM.cpp:421 */
+        float dzdy = ((float)ORC_D(r, c + 1) - (float)ORC_D(r, c - 1)) / 2.0f; /* SLAM.cpp:422 */
+        float dv[3] = {-dzdx, -dzdy, 1.0f};                                   /* SLAM.cpp:424 */
+        double nv = sqrt((double)dv[0] * dv[0] + (double)dv[1] * dv[1] + (double)dv[2] * dv[2]);
+        double sc = nv != 0.0 ? 1.0 / nv : 0.0; /* cv::normalize(Vec3f) */
+        ox = (float)(dv[0] * sc);
+        oy = (float)(dv[1] * sc);
+        oz = (float)(dv[2] * sc);
+      }
+      nx[n] = ox;
+      ny[n] = oy;
+      nz[n] = oz;
+      n++;
+    }
+#undef ORC_D
+  return n;
+}
+
+/* normals rotate with the cloud: n' = fl32(R n) (double accumulation)        */
+ORC_API void orc_rotate_normals(float *nx, float *ny, float *nz, int n, const float R[9]) {
+  const float zero[3] = {0.f, 0.f, 0.f};
+  orc_transform_points(nx, ny, nz, n, R, zero);
+}
+
+/* canonical sums of the linearised point-to-plane normal equations over the   */
+/* accepted pairs (dist < max_dist and a non-zero target normal):              */
+/*   J = [p x n ; n] (6), r = (p - q).n, sums[0..20] upper triangle of J J^T   */
+/*   row-major, sums[21..26] = J r, sums[27] = dist.  float64, same tree as    */
+/*   orc_sums_canonical.                                                        */
+ORC_API int64_t orc_sums_p2l_canonical(const float *ax, const float *ay, const float *az, int nq,
+                                       const float *tx, const float *ty, const float *tz,
+                                       const float *nx, const float *ny, const float *nz,
+                                       const int32_t *idx, const float *dist, float max_dist,
+                                       double sums[ORC_NP2L]) {
+  int B = (nq + ORC_RED_THREADS - 1) / ORC_RED_THREADS;
+  if (B < 1) B = 1;
+  if (B > ORC_RED_MAX_BLOCKS) B = ORC_RED_MAX_BLOCKS;
+  const int P = B * ORC_RED_THREADS;
+  double *acc = (double *)calloc((size_t)P * ORC_NP2L, sizeof(double));
+  int64_t count = 0;
+  for (int g = 0; g < P; g++) {
+    double *v = acc + (size_t)g * ORC_NP2L;
+    for (int i = g; i < nq; i += P) {
+      if (!(dist[i] < max_dist)) continue;
+      int j = idx[i];
+      double n[3] = {nx[j], ny[j], nz[j]};
+      if (n[0] == 0.0 && n[1] == 0.0 && n[2] == 0.0) continue;
+      double p[3] = {ax[i], ay[i], az[i]}, q[3] = {tx[j], ty[j], tz[j]};
+      double J[6];
+      J[0] = p[1] * n[2] - p[2] * n[1];
+      J[1] = p[2] * n[0] - p[0] * n[2];
+      J[2] = p[0] * n[1] - p[1] * n[0];
+      J[3] = n[0];
+      J[4] = n[1];
+      J[5] = n[2];
+      double r = ((p[0] - q[0]) * n[0] + (p[1] - q[1]) * n[1]) + (p[2] - q[2]) * n[2];
+      int k = 0;
+      for (int a = 0; a < 6; a++)
+        for (int b = a; b < 6; b++) v[k++] += J[a] * J[b];
+      for (int a = 0; a < 6; a++) v[21 + a] += J[a] * r;
+      v[27] += (double)dist[i];
+      count++;
+    }
+  }
+  for (int s = 0; s < ORC_NP2L; s++) sums[s] = 0.0;
+  for (int b = 0; b < B; b++) {
+    double wsum[4][ORC_NP2L];
+    for (int w = 0; w < 4; w++) {
+      double lane[64][ORC_NP2L], nxt[64][ORC_NP2L];
+      for (int l = 0; l < 64; l++)
+        memcpy(lane[l], acc + ((size_t)b * ORC_RED_THREADS + w * 64 + l) * ORC_NP2L, sizeof(double) * ORC_NP2L);
+      for (int m = 32; m >= 1; m >>= 1) {
+        for (int l = 0; l < 64; l++)
+          for (int s = 0; s < ORC_NP2L; s++) nxt[l][s] = lane[l][s] + lane[l ^ m][s];
+        memcpy(lane, nxt, sizeof(lane));
+      }
+      memcpy(wsum[w], lane[0], sizeof(double) * ORC_NP2L);
+    }
+    for (int s = 0; s < ORC_NP2L; s++) sums[s] += ((wsum[0][s] + wsum[1][s]) + wsum[2][s]) + wsum[3][s];
+  }
+  free(acc);
+  return count;
+}
+
+/* Solve A x = -b (6x6 SPD, Cholesky, float64), x = (alpha, t); R = exp([alpha]x)
+ * (Rodrigues).  Returns 0, or -1 if A is not positive definite.              */
+ORC_API int orc_solve_p2l(const double sums[ORC_NP2L], double R[9], double t[3]) {
+  double A[6][6], L[6][6] = {{0}}, x[6], yv[6];
+  int k = 0;
+  for (int a = 0; a < 6; a++)
+    for (int b = a; b < 6; b++) A[a][b] = A[b][a] = sums[k++];
+  double dmax = 0;
+  for (int a = 0; a < 6; a++)
+    if (A[a][a] > dmax) dmax = A[a][a];
+  for (int i = 0; i < 6; i++)
+    for (int j = 0; j <= i; j++) {
+      double s = A[i][j];
+      for (int m = 0; m < j; m++) s -= L[i][m] * L[j][m];
+      if (i == j) {
+        if (!(s > 1e-12 * dmax)) return -1;
+        L[i][i] = sqrt(s);
+      } else
+        L[i][j] = s / L[j][j];
+    }
+  for (int i = 0; i < 6; i++) {
+    double s = -sums[21 + i];
+    for (int m = 0; m < i; m++) s -= L[i][m] * yv[m];
+    yv[i] = s / L[i][i];
+  }
+  for (int i = 5; i >= 0; i--) {
+    double s = yv[i];
+    for (int m = i + 1; m < 6; m++) s -= L[m][i] * x[m];
+    x[i] = s / L[i][i];
+  }
+  double a0 = x[0], a1 = x[1], a2 = x[2];
+  double th2 = (a0 * a0 + a1 * a1) + a2 * a2, th = sqrt(th2);
+  double A1, B1;
+  if (th < 1e-9) {
+    A1 = 1.0 - th2 / 6.0;
+    B1 = 0.5 - th2 / 24.0;
+  } else {
+    A1 = sin(th) / th;
+    B1 = (1.0 - cos(th)) / th2;
+  }
+  double K[9] = {0, -a2, a1, a2, 0, -a0, -a1, a0, 0}, K2[9];
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 3; c++) K2[3 * r + c] = (K[3 * r] * K[c] + K[3 * r + 1] * K[3 + c]) + K[3 * r + 2] * K[6 + c];
+  for (int i = 0; i < 9; i++) R[i] = ((i % 4 == 0) ? 1.0 : 0.0) + (A1 * K[i] + B1 * K2[i]);
+  t[0] = x[3];
+  t[1] = x[4];
+  t[2] = x[5];
+  return 0;
+}
+
+/* ======================================================================== */
 /* Full loop.  Frame-pair formulation of icp.cpp:98-268 with the live        */
 /* keypoint association replaced by the full-cloud association the reference */
 /* keeps commented at icp.cpp:253 (findGlobalNearestNeighborAssociations).   */
@@ -654,10 +844,22 @@ typedef struct {
 } orc_result;
 
 static void nn_and_stats(float *sx, float *sy, float *sz, int ns, const float *tx,
-                         const float *ty, const float *tz, int nt, int32_t *idx,
+                         const float *ty, const float *tz, int nt, const float *nx,
+                         const float *ny, const float *nz, int32_t *idx,
                          float *dist, const orc_params *p, float *mse, int *npairs,
-                         double sums[ORC_NSUM]) {
+                         double sums[ORC_NP2L]) {
   orc_nn_bruteforce(sx, sy, sz, ns, tx, ty, tz, nt, idx, dist, p->threads);
+  if (p->solve == 2) { /* point-to-plane: pairs also need a valid target normal */
+    int64_t n = orc_sums_p2l_canonical(sx, sy, sz, ns, tx, ty, tz, nx, ny, nz, idx, dist,
+                                       p->max_nn_dist, sums);
+    *npairs = (int)n;
+    if (n > 0) {
+      float m = (float)(sums[27] / (double)n);
+      *mse = (float)((double)m * (double)m);
+    } else
+      *mse = 0.f;
+    return;
+  }
   if (p->sum_order == 0) {
     *mse = orc_mse_seq(dist, ns, p->max_nn_dist);
     int n = 0;
@@ -676,10 +878,12 @@ static void nn_and_stats(float *sx, float *sy, float *sz, int ns, const float *t
 }
 
 /* source arrays are transformed IN PLACE (like dataCloud in the reference). */
-ORC_API int orc_align(float *sx, float *sy, float *sz, int ns, const float *tx,
-                      const float *ty, const float *tz, int nt,
-                      const orc_params *p, float T[16], int32_t *idx, float *dist,
-                      orc_iter_trace *trace, orc_result *res) {
+/* nx/ny/nz: target normals (solve == 2 only, may be NULL otherwise).          */
+ORC_API int orc_align2(float *sx, float *sy, float *sz, int ns, const float *tx,
+                       const float *ty, const float *tz, int nt, const float *nx,
+                       const float *ny, const float *nz,
+                       const orc_params *p, float T[16], int32_t *idx, float *dist,
+                       orc_iter_trace *trace, orc_result *res) {
   static const float I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
   float Trot[9];
   float offset[3] = {0, 0, 0};
@@ -696,8 +900,12 @@ ORC_API int orc_align(float *sx, float *sy, float *sz, int ns, const float *tx,
   }
   float mse;
   int npairs;
-  double sums[ORC_NSUM];
-  nn_and_stats(sx, sy, sz, ns, tx, ty, tz, nt, idx, dist, p, &mse, &npairs, sums); /* icp.cpp:98 */
+  double sums[ORC_NP2L];
+  if (p->solve == 2 && (!nx || !ny || !nz)) {
+    res->status = -1;
+    return -1;
+  }
+  nn_and_stats(sx, sy, sz, ns, tx, ty, tz, nt, nx, ny, nz, idx, dist, p, &mse, &npairs, sums); /* icp.cpp:98 */
   int i = 0;
   while ((p->fixed_iterations || mse > p->threshold) && i < p->max_iterations) { /* icp.cpp:155 */
     if (npairs < p->min_pairs) { /* icp.cpp:163-182 */
@@ -736,6 +944,26 @@ ORC_API int orc_align(float *sx, float *sy, float *sz, int ns, const float *tx,
       memcpy(tr.M, M, sizeof(M));
       memcpy(tr.R, R, sizeof(R));
       memcpy(tr.t, offset, sizeof(offset));
+    } else if (p->solve == 2) {
+      double Rd[9], td[3];
+      if (orc_solve_p2l(sums, Rd, td) != 0) { /* degenerate normal equations */
+        res->status = 2;
+        break;
+      }
+      float Rf[9], tf[3];
+      for (int k = 0; k < 9; k++) Rf[k] = (float)Rd[k];
+      for (int k = 0; k < 3; k++) tf[k] = (float)td[k];
+      orc_transform_points(sx, sy, sz, ns, Rf, tf);
+      double Tn[12];
+      for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 4; c++) {
+          double sacc = 0;
+          for (int k = 0; k < 3; k++) sacc += (double)Rf[3 * r + k] * Tk[4 * k + c];
+          Tn[4 * r + c] = sacc + (c == 3 ? (double)tf[r] : 0.0);
+        }
+      memcpy(Tk, Tn, sizeof(Tk));
+      memcpy(tr.R, Rf, sizeof(Rf));
+      memcpy(tr.t, tf, sizeof(tf));
     } else {
       double sa[3], sb[3], sab[9], Rd[9], td[3];
       if (p->sum_order == 0) {
@@ -781,7 +1009,7 @@ ORC_API int orc_align(float *sx, float *sy, float *sz, int ns, const float *tx,
       memcpy(tr.t, tf, sizeof(tf));
     }
     if (trace) trace[i] = tr;
-    nn_and_stats(sx, sy, sz, ns, tx, ty, tz, nt, idx, dist, p, &mse, &npairs, sums); /* icp.cpp:255 */
+    nn_and_stats(sx, sy, sz, ns, tx, ty, tz, nt, nx, ny, nz, idx, dist, p, &mse, &npairs, sums); /* icp.cpp:255 */
     i++; /* icp.cpp:257 */
   }
   res->iterations = i;
@@ -797,6 +1025,13 @@ ORC_API int orc_align(float *sx, float *sy, float *sz, int ns, const float *tx,
       for (int c = 0; c < 4; c++) T[4 * r + c] = (float)Tk[4 * r + c];
   }
   return res->status;
+}
+
+ORC_API int orc_align(float *sx, float *sy, float *sz, int ns, const float *tx,
+                      const float *ty, const float *tz, int nt,
+                      const orc_params *p, float T[16], int32_t *idx, float *dist,
+                      orc_iter_trace *trace, orc_result *res) {
+  return orc_align2(sx, sy, sz, ns, tx, ty, tz, nt, NULL, NULL, NULL, p, T, idx, dist, trace, res);
 }
 
 ORC_API int orc_sizeof_params(void) { return (int)sizeof(orc_params); }

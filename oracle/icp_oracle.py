@@ -15,6 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "_build", "libicp_oracle.so")
 
 NSUM = 19
+NP2L = 28
 RED_THREADS = 256
 RED_MAX_BLOCKS = 256
 
@@ -236,6 +237,41 @@ def backproject(depth, keep=None, fx=468.60, cx=318.27):
     return np.stack([x[:m], y[:m], z[:m]])
 
 
+def backproject_normals(depth, mode=0, fx=468.60, cx=318.27):
+    """Returns (points (3,N), normals (3,N)) in the row-major order of valid pixels."""
+    depth = np.ascontiguousarray(depth, np.uint16)
+    rows, cols = depth.shape
+    n = rows * cols
+    arrs = [np.empty(n, np.float32) for _ in range(6)]
+    m = lib().orc_backproject_normals(_p(depth, C.c_uint16), C.c_int(rows), C.c_int(cols), C.c_float(fx),
+                                      C.c_float(cx), C.c_int(mode), *[_p(a) for a in arrs])
+    return np.stack([a[:m] for a in arrs[:3]]), np.stack([a[:m] for a in arrs[3:]])
+
+
+def rotate_normals(nrm, R):
+    x, y, z = (_f(nrm[k]).copy() for k in range(3))
+    R = _f(R).reshape(9)
+    lib().orc_rotate_normals(_p(x), _p(y), _p(z), C.c_int(x.size), _p(R))
+    return np.stack([x, y, z])
+
+
+def sums_p2l_canonical(src, tgt, nrm, idx, dist, max_dist):
+    keep, a = _assoc_args(src, tgt, idx, dist)
+    nx, ny, nz = (_f(nrm[k]) for k in range(3))
+    out = np.zeros(NP2L, np.float64)
+    args = a[:7] + [_p(nx), _p(ny), _p(nz)] + a[7:]
+    n = lib().orc_sums_p2l_canonical(*args, C.c_float(max_dist), _p(out, C.c_double))
+    return out, int(n)
+
+
+def solve_p2l(sums):
+    sums = np.ascontiguousarray(sums, np.float64)
+    R = np.zeros((3, 3))
+    t = np.zeros(3)
+    rc = lib().orc_solve_p2l(_p(sums, C.c_double), _p(R, C.c_double), _p(t, C.c_double))
+    return R, t, rc
+
+
 def depth_range_filter(depth, max_d=25000, min_d=1000):
     d = np.ascontiguousarray(depth, np.uint16).copy()
     lib().orc_depth_range_filter(_p(d, C.c_uint16), C.c_int(d.size), C.c_int(max_d), C.c_int(min_d))
@@ -244,7 +280,7 @@ def depth_range_filter(depth, max_d=25000, min_d=1000):
 
 def align(src, tgt, max_iterations=16, threshold=1e-4, max_nn_dist=0.75, min_pairs=3,
           solve=0, sum_order=0, fixed_iterations=False, threads=1,
-          last_rotation=None, last_translation=None):
+          last_rotation=None, last_translation=None, normals=None):
     """Runs the restated loop.  Returns dict(T, src_out, idx, dist, trace, result)."""
     sx, sy, sz = (_f(src[k]).copy() for k in range(3))
     tx, ty, tz = (_f(tgt[k]) for k in range(3))
@@ -266,9 +302,14 @@ def align(src, tgt, max_iterations=16, threshold=1e-4, max_nn_dist=0.75, min_pai
     dist = np.zeros(sx.size, np.float32)
     trace = (IterTrace * max(1, max_iterations))()
     res = Result()
-    lib().orc_align(_p(sx), _p(sy), _p(sz), C.c_int(sx.size), _p(tx), _p(ty), _p(tz),
-                    C.c_int(tx.size), C.byref(p), _p(T), _p(idx, C.c_int32), _p(dist),
-                    trace, C.byref(res))
+    if normals is not None:
+        nx, ny, nz = (_f(normals[k]) for k in range(3))
+        npt = [_p(nx), _p(ny), _p(nz)]
+    else:
+        npt = [None, None, None]
+    lib().orc_align2(_p(sx), _p(sy), _p(sz), C.c_int(sx.size), _p(tx), _p(ty), _p(tz),
+                     C.c_int(tx.size), *npt, C.byref(p), _p(T), _p(idx, C.c_int32), _p(dist),
+                     trace, C.byref(res))
     tr = []
     for i in range(res.iterations):
         tr.append(dict(n_pairs=trace[i].n_pairs, mse=np.float32(trace[i].mse),

@@ -473,3 +473,93 @@ def test_transform_target_commit_and_trace(ctx, oracle):
     for a, b in zip(tr, o["trace"]):
         assert np.array_equal(a["R"], b["R"]) and np.array_equal(a["t"], b["t"])
         assert a["n_pairs"] == b["n_pairs"] and a["mse"] == b["mse"]
+
+
+# ------------------------------------------- point-to-plane extension (config 3) --
+@pytest.mark.parametrize("mode", [binding.NORMALS_CROSS, binding.NORMALS_REFERENCE])
+def test_backproject_normals_bit_exact(ctx, oracle, mode):
+    rng = np.random.default_rng(31)
+    fx, cx = float(synth.K2_FX), float(synth.K2_CX)
+    for rows, cols, frac in [(60, 80, 1.0), (106, 128, 0.9), (424, 512, 0.97)]:
+        p = synth.kinect_pair(rows=rows, cols=cols, valid=1.0, seed=6, fx=fx * cols / 512, cx=cx * cols / 512)
+        depth = p["depth_tgt"].copy()
+        depth[rng.random(depth.shape) >= frac] = 0
+        pts, nrm = oracle.backproject_normals(depth, mode, fx=fx * cols / 512, cx=cx * cols / 512)
+        n = ctx.backproject_with_normals(depth, mode, fx=fx * cols / 512, cx=cx * cols / 512, offset=[5, 5, 5])
+        assert n == pts.shape[1]
+        assert np.array_equal(ctx.get_target(), pts + np.float32(5))
+        got = ctx.get_target_normals()
+        assert np.array_equal(got.view(np.uint32), nrm.view(np.uint32))
+        assert (np.abs(nrm).sum(0) > 0).mean() > 0.5
+
+
+def test_reduce_p2l_bit_exact_and_rotating_normals(ctx, oracle):
+    fx, cx = float(synth.K2_FX) / 2, float(synth.K2_CX) / 2
+    p = synth.kinect_pair(rows=212, cols=256, valid=1.0, seed=8, fx=fx, cx=cx)
+    pts, nrm = oracle.backproject_normals(p["depth_tgt"], 0, fx=fx, cx=cx)
+    tgt = pts + np.float32(5)
+    ctx.backproject_with_normals(p["depth_tgt"], 0, fx=fx, cx=cx, offset=[5, 5, 5])
+    ctx.set_source(p["source"])
+    idx, dist = ctx.nn()
+    sums, cnt = ctx.reduce_p2l(0.3)
+    osums, ocnt = oracle.sums_p2l_canonical(p["source"], tgt, nrm, idx, dist, 0.3)
+    assert cnt == ocnt > 1000
+    assert np.array_equal(sums.view(np.uint64), osums.view(np.uint64))
+    R, t, rc = binding.solve_point_to_plane(sums)
+    Ro, to, rco = oracle.solve_p2l(osums)
+    assert rc == rco == 0 and np.allclose(R, Ro, atol=1e-13) and np.allclose(t, to, atol=1e-13)
+    # normals given from the host, then rotated together with the target
+    ctx.set_target(tgt)
+    ctx.set_target_normals(nrm)
+    Rm = oracle.make_rotation_matrix(2, -3, 1)
+    ctx.transform_target(Rm, np.array([0.1, 0.2, 0.3], np.float32))
+    assert np.array_equal(ctx.get_target_normals().view(np.uint32), oracle.rotate_normals(nrm, Rm).view(np.uint32))
+    with pytest.raises(binding.IcpkError):
+        ctx.set_target_normals(nrm[:, :10])
+
+
+def test_align_point_to_plane_matches_oracle(ctx, oracle):
+    fx, cx = float(synth.K2_FX) / 4, float(synth.K2_CX) / 4
+    p = synth.kinect_pair(rows=106, cols=128, valid=1.0, seed=4, noise_sigma=0.0005, fx=fx, cx=cx)
+    pts, nrm = oracle.backproject_normals(p["depth_tgt"], 0, fx=fx, cx=cx)
+    tgt = pts + np.float32(5)
+    ctx.backproject_with_normals(p["depth_tgt"], 0, fx=fx, cx=cx, offset=[5, 5, 5])
+    ctx.set_source(p["source"])
+    for mode in (binding.NN_EXACT, binding.NN_PRUNED):
+        T, st, rc = ctx.align(solve=binding.SOLVE_POINT_TO_PLANE, max_iterations=10, fixed_iterations=1,
+                              max_nn_dist=0.3, nn_mode=mode)
+        o = oracle.align(p["source"], tgt, max_iterations=10, solve=2, sum_order=1, fixed_iterations=True, threads=8,
+                         normals=nrm, max_nn_dist=0.3)
+        assert rc == 0 and st.iterations == o["iterations"] == 10 and st.final_pairs == o["final_pairs"]
+        assert np.linalg.norm(T.astype(np.float64) - o["T"].astype(np.float64)) < 1e-5
+        assert np.array_equal(T, o["T"])
+        idx, dist = ctx.get_associations()
+        assert np.array_equal(idx, o["idx"]) and np.array_equal(ctx.get_source(), o["src_out"])
+    Rt, tt = p["R_true"], p["t_true"]
+    assert np.linalg.norm(T[:3, :3].astype(np.float64) - Rt) < 3e-3
+    # without normals the solve flavour is refused
+    ctx.set_target(tgt)
+    with pytest.raises(binding.IcpkError) as e:
+        ctx.align(solve=binding.SOLVE_POINT_TO_PLANE)
+    assert e.value.code == binding.E_NOT_SET
+
+
+def test_config3_full_size_properties(ctx):
+    """BASELINE config 3 at full size (512x424, ~217k points, point-to-plane): exact
+    and pruned NN kernels give the same alignment bit for bit; the result approaches
+    the true motion; normals are unit length."""
+    fx, cx = float(synth.K2_FX), float(synth.K2_CX)
+    p = synth.kinect_pair(rows=424, cols=512, valid=1.0, seed=3, noise_sigma=0.0005, fx=fx, cx=cx)
+    n = ctx.backproject_with_normals(p["depth_tgt"], 0, fx=fx, cx=cx, offset=[5, 5, 5])
+    assert n == p["target"].shape[1] > 200000
+    nrm = ctx.get_target_normals().astype(np.float64)
+    ln = np.linalg.norm(nrm, axis=0)
+    assert np.all((ln == 0) | (np.abs(ln - 1) < 1e-6)) and (ln > 0).mean() > 0.9
+    ctx.set_source(p["source"])
+    T1, st1, _ = ctx.align(solve=binding.SOLVE_POINT_TO_PLANE, max_iterations=3, fixed_iterations=1, max_nn_dist=0.3,
+                           nn_mode=binding.NN_FILTERED)
+    T2, st2, _ = ctx.align(solve=binding.SOLVE_POINT_TO_PLANE, max_iterations=3, fixed_iterations=1, max_nn_dist=0.3,
+                           nn_mode=binding.NN_PRUNED)
+    assert np.array_equal(T1, T2) and st1.final_pairs == st2.final_pairs
+    T3, st3, _ = ctx.align(solve=binding.SOLVE_POINT_TO_PLANE, max_iterations=15, fixed_iterations=1, max_nn_dist=0.3)
+    assert np.linalg.norm(T3[:3, :3].astype(np.float64) - p["R_true"]) < 2e-3

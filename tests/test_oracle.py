@@ -373,3 +373,95 @@ def test_align_threshold_exit_and_fallback(oracle):
     r = oracle.align(far, p["target"], max_iterations=16, threshold=1e-4, solve=0)
     assert r["final_pairs"] == 0 and r["status"] == 0 and r["iterations"] == 0
     assert np.array_equal(r["T"], np.eye(4, dtype=np.float32))
+
+
+# ------------------------------------------------ point-to-plane (unpinned) --
+def test_normals_modes(oracle):
+    """mode 0 on a tilted plane gives the plane normal; mode 1 is the literal
+    SLAM.cpp:421-425 formula (checked against a numpy restatement)."""
+    rows, cols = 40, 50
+    v, u = np.mgrid[0:rows, 0:cols].astype(np.float64)
+    # plane n.p = h seen from the origin with the reference's pinhole
+    n_true = np.array([0.2, -0.1, 1.0])
+    n_true /= np.linalg.norm(n_true)
+    d = np.stack([(u - float(synth.CX)) / float(synth.FX), (v - float(synth.CX)) / float(synth.FX), np.ones_like(u)], -1)
+    z = 2.0 / (d @ n_true)
+    depth = np.rint(z * 5000).astype(np.uint16)
+    depth[5, 7] = 0
+    pts, nrm = oracle.backproject_normals(depth, 0)
+    assert np.array_equal(pts, oracle.backproject(depth))
+    valid = np.abs(nrm).sum(0) > 0
+    assert 0.8 < valid.mean() < 1.0
+    cosang = np.abs(nrm[:, valid].T.astype(np.float64) @ n_true)
+    assert cosang.min() > 0.999  # quantised depth: within ~2.5 degrees
+    assert np.allclose(np.linalg.norm(nrm[:, valid].astype(np.float64), axis=0), 1, atol=1e-6)
+    # the hole at (5,7) invalidates its 4 neighbours' normals and the border has none
+    r, c = np.nonzero(depth)
+    k = np.flatnonzero((r == 5) & (c == 8))[0]
+    assert not valid[k] and not valid[0]
+    # mode 1
+    pts1, n1 = oracle.backproject_normals(depth, 1)
+    img = depth.astype(np.float32)
+    want = np.zeros((rows, cols, 3), np.float32)
+    dzdx = (img[2:, 1:-1] - img[:-2, 1:-1]) / np.float32(2)
+    dzdy = (img[1:-1, 2:] - img[1:-1, :-2]) / np.float32(2)
+    dv = np.stack([-dzdx, -dzdy, np.ones_like(dzdx)], -1).astype(np.float64)
+    nv = np.sqrt((dv[..., 0] ** 2 + dv[..., 1] ** 2) + dv[..., 2] ** 2)
+    want[1:-1, 1:-1] = (dv * (1.0 / nv)[..., None]).astype(np.float32)
+    assert np.array_equal(n1.T, want[r, c])
+
+
+def test_p2l_sums_and_solve(oracle):
+    rng = np.random.default_rng(21)
+    n = 4000
+    tgt = (rng.uniform(-2, 2, (3, 900)) + 5).astype(np.float32)
+    nrm = rng.normal(size=(3, 900))
+    nrm = (nrm / np.linalg.norm(nrm, axis=0)).astype(np.float32)
+    nrm[:, ::7] = 0  # invalid normals never pair
+    idx = rng.integers(0, 900, n).astype(np.int32)
+    src = (tgt[:, idx] + rng.normal(0, 0.02, (3, n))).astype(np.float32)
+    dist = np.linalg.norm(src - tgt[:, idx], axis=0).astype(np.float32)
+    sums, cnt = oracle.sums_p2l_canonical(src, tgt, nrm, idx, dist, 0.05)
+    acc = (dist < np.float32(0.05)) & (np.abs(nrm[:, idx]).sum(0) > 0)
+    assert cnt == acc.sum() and 0 < cnt < n
+    p = src.astype(np.float64).T[acc]
+    q = tgt[:, idx].astype(np.float64).T[acc]
+    nn = nrm[:, idx].astype(np.float64).T[acc]
+    J = np.concatenate([np.cross(p, nn), nn], axis=1)
+    r = ((p - q) * nn).sum(1)
+    A = J.T @ J
+    assert np.allclose(sums[:21], A[np.triu_indices(6)], rtol=1e-11)
+    assert np.allclose(sums[21:27], J.T @ r, rtol=1e-9, atol=1e-12)
+    assert np.isclose(sums[27], dist[acc].astype(np.float64).sum(), rtol=1e-12)
+    R, t, rc = oracle.solve_p2l(sums)
+    x = np.linalg.solve(A, -(J.T @ r))
+    assert rc == 0 and np.allclose(t, x[3:], atol=1e-10)
+    from scipy.spatial.transform import Rotation
+
+    assert np.allclose(R, Rotation.from_rotvec(x[:3]).as_matrix(), atol=1e-12)
+    # rank-deficient normal equations (all normals parallel) are reported, not solved
+    nrm2 = np.zeros_like(nrm)
+    nrm2[2] = 1
+    sums2, _ = oracle.sums_p2l_canonical(src, tgt, nrm2, idx, dist, 0.05)
+    assert oracle.solve_p2l(sums2)[2] == -1
+
+
+def test_align_point_to_plane_converges_config3_small(oracle):
+    """Config 3 shape at 1/4 resolution: dense Kinect-v2-like pair, normals from
+    the depth image; point-to-plane gets much closer than point-to-point."""
+    fx, cx = float(synth.K2_FX) / 4, float(synth.K2_CX) / 4
+    p = synth.kinect_pair(rows=106, cols=128, valid=1.0, seed=4, noise_sigma=0.0005, fx=fx, cx=cx)
+    tp, tn = oracle.backproject_normals(p["depth_tgt"], 0, fx=fx, cx=cx)
+    tgt = (tp + np.float32(5)).astype(np.float32)
+    assert np.array_equal(tgt, p["target"])
+    Rt, tt = p["R_true"], p["t_true"]
+    t_want = tt + 5 - Rt @ np.full(3, 5.0)
+    errs = {}
+    for solve in (1, 2):
+        r = oracle.align(p["source"], tgt, max_iterations=20, threshold=0, solve=solve, sum_order=1, threads=8,
+                         normals=tn, max_nn_dist=0.3)
+        T = r["T"].astype(np.float64)
+        errs[solve] = (np.linalg.norm(T[:3, :3] - Rt), np.linalg.norm(T[:3, 3] - t_want))
+        assert r["status"] == 0 and r["iterations"] == 20
+    assert errs[2][0] < 2e-3 and errs[2][1] < 5e-3
+    assert errs[2][0] < errs[1][0] / 5
