@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--iters", type=int, default=20, help="fixed ICP iterations per step (config 2: 20)")
     ap.add_argument("--workload", default="kinect640x480_30pct",
                     choices=["kinect640x480_30pct", "kinect640x480_dense", "kinect_v2_512x424", "dense1m", "frustum10k"])
-    ap.add_argument("--solve", default="reference", choices=["reference", "kabsch"])
+    ap.add_argument("--solve", default="reference", choices=["reference", "kabsch", "p2l"])
     ap.add_argument("--nn-mode", default="pruned", choices=["exact", "filtered", "pruned"],
                     help="all three give bit-identical results; pruned is the product default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -143,9 +143,16 @@ def main():
     ctx.set_target_device(tgt_d.data_ptr(), tgt_d.data_ptr() + nt * es, tgt_d.data_ptr() + 2 * nt * es, nt)
     ctx.set_source_device(src_d.data_ptr(), src_d.data_ptr() + nq * es, src_d.data_ptr() + 2 * nq * es, nq)
 
+    if args.solve == "p2l":
+        # point-to-plane (config 3): the target and its normals come from the depth image
+        kw = dict(fx=float(w.get("fx", 468.60)), cx=float(w.get("cx", 318.27)))
+        ctx.backproject_with_normals(w["depth_tgt"], binding.NORMALS_CROSS, offset=[5, 5, 5], **kw)
+        assert ctx.target_size == nt
     params = binding.default_params(
         max_iterations=args.iters, fixed_iterations=1, profile=1,
-        solve=binding.SOLVE_REFERENCE if args.solve == "reference" else binding.SOLVE_KABSCH,
+        max_nn_dist=0.3 if args.solve == "p2l" else 0.75,
+        solve={"reference": binding.SOLVE_REFERENCE, "kabsch": binding.SOLVE_KABSCH,
+               "p2l": binding.SOLVE_POINT_TO_PLANE}[args.solve],
         nn_mode={"exact": binding.NN_EXACT, "filtered": binding.NN_FILTERED, "pruned": binding.NN_PRUNED}[args.nn_mode])
 
     def sync_all():

@@ -47,6 +47,19 @@ struct icpk_ctx {
   bool have_boxes = false; // boxes match tgt
   float* boxes = nullptr;  // [6][tbox_stride] tile boxes then [6][sbox_stride] sub-tile boxes
   int boxes_tiles_cap = 0;
+  // pruned scan: Morton-ordered copy of the target, its permutation, the query order
+  Cloud sorted;
+  int* tperm = nullptr;
+  int tperm_cap = 0;
+  int* qperm = nullptr;
+  int qperm_cap = 0;
+  bool have_qperm = false;
+  float* bounds = nullptr;  // 6 floats: lo xyz, hi xyz of the target
+  unsigned* sort_keys = nullptr;  // 2 x sort_cap
+  int* sort_vals = nullptr;       // sort_cap
+  int sort_cap = 0;
+  void* sort_temp = nullptr;
+  size_t sort_temp_bytes = 0;
   bool have_seed = false;  // `best` holds matches of a previous sweep of the same clouds
   nn_key_t* best = nullptr;
   nn_key_t* seed = nullptr;
@@ -184,6 +197,90 @@ int check_ready(icpk_ctx* ctx) {
   return ICPK_OK;
 }
 
+int ensure_sort_buffers(icpk_ctx* ctx, int n) {
+  const int cap = round_up(n < 1 ? 1 : n, NN_TILE);
+  if (cap > ctx->sort_cap) {
+    if (ctx->sort_keys) ICPK_HIP(ctx, hipFree(ctx->sort_keys));
+    if (ctx->sort_vals) ICPK_HIP(ctx, hipFree(ctx->sort_vals));
+    ctx->sort_keys = nullptr;
+    ctx->sort_vals = nullptr;
+    ctx->sort_cap = 0;
+    ICPK_HIP(ctx, hipMalloc((void**)&ctx->sort_keys, (size_t)2 * cap * sizeof(unsigned)));
+    ICPK_HIP(ctx, hipMalloc((void**)&ctx->sort_vals, (size_t)cap * sizeof(int)));
+    ctx->sort_cap = cap;
+  }
+  const size_t need = sort_temp_bytes(n);
+  if (need > ctx->sort_temp_bytes) {
+    if (ctx->sort_temp) ICPK_HIP(ctx, hipFree(ctx->sort_temp));
+    ctx->sort_temp = nullptr;
+    ctx->sort_temp_bytes = 0;
+    ICPK_HIP(ctx, hipMalloc(&ctx->sort_temp, need));
+    ctx->sort_temp_bytes = need;
+  }
+  if (!ctx->bounds) ICPK_HIP(ctx, hipMalloc((void**)&ctx->bounds, 6 * sizeof(float)));
+  return ICPK_OK;
+}
+
+// Morton order of `c` (keys from the target's bounds) -> perm_out[k] = index of the k-th point
+int enqueue_morton_order(icpk_ctx* ctx, const Cloud& c, int* perm_out) {
+  int rc = ensure_sort_buffers(ctx, c.n);
+  if (rc) return rc;
+  unsigned* ka = ctx->sort_keys;
+  unsigned* kb = ctx->sort_keys + ctx->sort_cap;
+  launch_morton(c.x(), c.y(), c.z(), c.n, ctx->bounds, ka, ctx->sort_vals, ctx->stream);
+  if (launch_sort_pairs(ctx->sort_temp, ctx->sort_temp_bytes, ka, kb, ctx->sort_vals, perm_out, c.n, ctx->stream) != 0)
+    return fail(ctx, ICPK_E_HIP, "rocprim::radix_sort_pairs failed");
+  return ICPK_OK;
+}
+
+// boxes + Morton-ordered target for the pruned scan (once per target cloud)
+int prepare_pruned_target(icpk_ctx* ctx, NnBoxes& bx) {
+  const int nt = ctx->tgt.n;
+  const int nt_pad = round_up(nt, NN_TILE);
+  const int ntiles = nt_pad / NN_TILE;
+  if (ntiles > ctx->boxes_tiles_cap) {
+    if (ctx->boxes) ICPK_HIP(ctx, hipFree(ctx->boxes));
+    ctx->boxes = nullptr;
+    ctx->boxes_tiles_cap = 0;
+    ICPK_HIP(ctx, hipMalloc((void**)&ctx->boxes, (size_t)6 * (ntiles + 16) * (1 + NN_SUBS) * sizeof(float)));
+    ctx->boxes_tiles_cap = ntiles;
+    ctx->have_boxes = false;
+  }
+  if (nt_pad > ctx->tperm_cap) {
+    if (ctx->tperm) ICPK_HIP(ctx, hipFree(ctx->tperm));
+    ctx->tperm = nullptr;
+    ctx->tperm_cap = 0;
+    ICPK_HIP(ctx, hipMalloc((void**)&ctx->tperm, ((size_t)nt_pad + 64) * sizeof(int)));
+    ctx->tperm_cap = nt_pad;
+    ctx->have_boxes = false;
+  }
+  bx.tbox_stride = ctx->boxes_tiles_cap + 16;
+  bx.sbox_stride = (ctx->boxes_tiles_cap + 16) * NN_SUBS;
+  bx.tbox = ctx->boxes;
+  bx.sbox = ctx->boxes + (size_t)6 * bx.tbox_stride;
+  bx.ox = ctx->tgt.x();
+  bx.oy = ctx->tgt.y();
+  bx.oz = ctx->tgt.z();
+  bx.tperm = ctx->tperm;
+  bx.qperm = ctx->qperm;
+  if (ctx->have_boxes) return ICPK_OK;
+  int rc = ensure_cloud(ctx, ctx->sorted, nt);
+  if (rc) return rc;
+  rc = ensure_sort_buffers(ctx, nt);
+  if (rc) return rc;
+  // bounds of the cloud from boxes of the caller's order, then sort, gather, final boxes
+  launch_tile_boxes(ctx->tgt.x(), ctx->tgt.y(), ctx->tgt.z(), nt, ntiles, bx, ctx->stream);
+  launch_bounds(bx.tbox, bx.tbox_stride, ntiles, ctx->bounds, ctx->stream);
+  rc = enqueue_morton_order(ctx, ctx->tgt, ctx->tperm);
+  if (rc) return rc;
+  launch_gather_planes(ctx->tgt.x(), ctx->tgt.y(), ctx->tgt.z(), ctx->tperm, nt, nt_pad, __builtin_inff(),
+                       ctx->sorted.x(), ctx->sorted.y(), ctx->sorted.z(), ctx->tperm, ctx->stream);
+  launch_tile_boxes(ctx->sorted.x(), ctx->sorted.y(), ctx->sorted.z(), nt, ntiles, bx, ctx->stream);
+  ICPK_HIP(ctx, hipGetLastError());
+  ctx->have_boxes = true;
+  return ICPK_OK;
+}
+
 // enqueue one NN sweep (K1) over the working source
 int enqueue_nn(icpk_ctx* ctx, int nn_mode) {
   if (nn_mode != ICPK_NN_EXACT && nn_mode != ICPK_NN_FILTERED && nn_mode != ICPK_NN_PRUNED)
@@ -247,22 +344,24 @@ int enqueue_nn(icpk_ctx* ctx, int nn_mode) {
     NnBoxes bx;
     const NnBoxes* pbx = nullptr;
     if (nn_mode == ICPK_NN_PRUNED) {
-      if (ntiles > ctx->boxes_tiles_cap) {
-        if (ctx->boxes) ICPK_HIP(ctx, hipFree(ctx->boxes));
-        ctx->boxes = nullptr;
-        ctx->boxes_tiles_cap = 0;
-        ICPK_HIP(ctx, hipMalloc((void**)&ctx->boxes, (size_t)6 * (ntiles + 16) * (1 + NN_SUBS) * sizeof(float)));
-        ctx->boxes_tiles_cap = ntiles;
-        ctx->have_boxes = false;
+      if (round_up(nq, NN_TILE) > ctx->qperm_cap) {
+        if (ctx->qperm) ICPK_HIP(ctx, hipFree(ctx->qperm));
+        ctx->qperm = nullptr;
+        ctx->qperm_cap = 0;
+        ICPK_HIP(ctx, hipMalloc((void**)&ctx->qperm, (size_t)round_up(nq, NN_TILE) * sizeof(int)));
+        ctx->qperm_cap = round_up(nq, NN_TILE);
+        ctx->have_qperm = false;
       }
-      bx.tbox_stride = ctx->boxes_tiles_cap + 16;
-      bx.sbox_stride = (ctx->boxes_tiles_cap + 16) * NN_SUBS;
-      bx.tbox = ctx->boxes;
-      bx.sbox = ctx->boxes + (size_t)6 * bx.tbox_stride;
-      if (!ctx->have_boxes) {
-        launch_tile_boxes(a.tx, a.ty, a.tz, ctx->tgt.n, ntiles, bx, ctx->stream);
-        ctx->have_boxes = true;
+      rc = prepare_pruned_target(ctx, bx);
+      if (rc) return rc;
+      if (!ctx->have_qperm) {  // query order: Morton order of the source at its current pose
+        rc = enqueue_morton_order(ctx, ctx->src, ctx->qperm);
+        if (rc) return rc;
+        ctx->have_qperm = true;
       }
+      a.tx = ctx->sorted.x();
+      a.ty = ctx->sorted.y();
+      a.tz = ctx->sorted.z();
       pbx = &bx;
     }
     const int q = ctx->q_per_lane > 0 ? ctx->q_per_lane : (nq >= 65536 ? 2 : 1);
@@ -361,7 +460,8 @@ void icpk_destroy(icpk_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   for (hipEvent_t e : ctx->events) (void)hipEventDestroy(e);
-  void* dev[] = {ctx->nrm.base, ctx->boxes, ctx->dec.base, ctx->tgt.base, ctx->src0.base, ctx->src.base, ctx->best,      ctx->seed,     ctx->idx,
+  void* dev[] = {ctx->sorted.base, ctx->tperm, ctx->qperm, ctx->bounds, ctx->sort_keys, ctx->sort_vals, ctx->sort_temp,
+                 ctx->nrm.base, ctx->boxes, ctx->dec.base, ctx->tgt.base, ctx->src0.base, ctx->src.base, ctx->best,      ctx->seed,     ctx->idx,
                  ctx->dist,     ctx->partial,   ctx->pcount,   ctx->red_out,   ctx->depth_dev, ctx->bp_counts};
   for (void* p : dev)
     if (p) (void)hipFree(p);
@@ -405,6 +505,7 @@ static int set_source_impl(icpk_ctx* ctx, const float* x, const float* y, const 
   ctx->have_src = true;
   ctx->have_assoc = false;
   ctx->have_seed = false;
+  ctx->have_qperm = false;
   rc = copy_src0_to_src(ctx);
   if (rc) return rc;
   ICPK_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -432,6 +533,7 @@ int icpk_reset_source(icpk_ctx* ctx) {
   if (rc) return rc;
   ctx->have_assoc = false;
   ctx->have_seed = false;
+  ctx->have_qperm = false;
   ICPK_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return ICPK_OK;
 }
@@ -597,6 +699,7 @@ int icpk_align(icpk_ctx* ctx, const icpk_params* p, float T_out[16], icpk_stats*
   rc = copy_src0_to_src(ctx);
   if (rc) return rc;
   ctx->have_seed = false;  // matches of an earlier alignment belong to a different source pose
+  ctx->have_qperm = false;
 
   const bool prof = p->profile != 0;
   size_t nev = 0;
@@ -861,6 +964,7 @@ static int backproject_impl(icpk_ctx* ctx, const uint16_t* depth, int32_t rows, 
   ICPK_HIP(ctx, hipGetLastError());
   ctx->have_assoc = false;
   ctx->have_seed = false;
+  ctx->have_qperm = false;
   if (which == 1) {
     ctx->have_dec = ctx->have_boxes = false;
     ctx->have_normals = normals_mode >= 0;

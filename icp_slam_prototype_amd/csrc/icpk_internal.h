@@ -63,7 +63,25 @@ struct NnBoxes {
   int tbox_stride;  // floats per plane
   float* sbox;
   int sbox_stride;
+  // pruned scan only: NnArgs::tx/ty/tz are the Morton-ordered planes the boxes were
+  // built on; ox/oy/oz the target in the caller's order (seed look-up); tperm maps a
+  // scanned position to the original index; qperm lists the queries in Morton order
+  const float* ox;
+  const float* oy;
+  const float* oz;
+  const int* tperm;
+  const int* qperm;
 };
+
+// kernels_sort.hip
+void launch_bounds(const float* tbox, int tbox_stride, int ntiles, float* bounds, hipStream_t s);
+void launch_morton(const float* x, const float* y, const float* z, int n, const float* bounds, unsigned* keys, int* vals,
+                   hipStream_t s);
+size_t sort_temp_bytes(int n);
+int launch_sort_pairs(void* temp, size_t temp_bytes, const unsigned* keys_in, unsigned* keys_out, const int* vals_in,
+                      int* vals_out, int n, hipStream_t s);
+void launch_gather_planes(const float* x, const float* y, const float* z, const int* perm, int n, int n_pad, float pad,
+                          float* ox, float* oy, float* oz, int* perm_pad, hipStream_t s);
 // boxes == nullptr: brute force over every target
 void launch_nn_filtered(const NnArgs& a, const nn_key_t* seed, int seed_scale, int q_per_lane, const NnBoxes* boxes,
                         hipStream_t s);

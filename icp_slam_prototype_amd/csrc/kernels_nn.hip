@@ -178,11 +178,13 @@ __device__ __forceinline__ void group_estimates(const float (&qx)[Q], const floa
 // slow path, entered when some lane's minimum passed its threshold: walk the group
 // and re-evaluate exactly only those targets some lane still passes (wave-uniform
 // branch per target); lexicographic (d, j) merge; thresholds tighten as we go
-template <int Q>
+// PERM: the scanned planes are a permutation of the caller's cloud; tperm[j] is the
+// original index, which is what the lowest-index tie rule and the result refer to.
+template <int Q, bool PERM>
 __device__ __forceinline__ void group_exact(const float (&qx)[Q], const float (&qy)[Q], const float (&qz)[Q],
                                             const float (&X)[NNF_G], const float (&Y)[NNF_G], const float (&Z)[NNF_G],
-                                            const float (&e)[NNF_G][Q], int j, float (&bd)[Q], int (&bj)[Q],
-                                            float (&T)[Q]) {
+                                            const float (&e)[NNF_G][Q], int j, const int* __restrict__ tperm,
+                                            float (&bd)[Q], int (&bj)[Q], float (&T)[Q]) {
 #pragma unroll
   for (int k = 0; k < NNF_G; ++k) {
     bool hit = false;
@@ -192,7 +194,7 @@ __device__ __forceinline__ void group_exact(const float (&qx)[Q], const float (&
 #pragma unroll
       for (int u = 0; u < Q; ++u) {
         const float d = pair_dist(qx[u], qy[u], qz[u], X[k], Y[k], Z[k]);
-        const int jj = j + k;
+        const int jj = PERM ? tperm[j + k] : j + k;  // uniform address: scalar load
         const bool up = (d < bd[u]) | ((d == bd[u]) & (jj < bj[u]));
         bd[u] = up ? d : bd[u];
         bj[u] = up ? jj : bj[u];
@@ -206,9 +208,10 @@ __device__ __forceinline__ void group_exact(const float (&qx)[Q], const float (&
 // Two SGPR buffers (A, B) of NNF_G targets: the scalar loads of one group are in
 // flight while the other is consumed.  The last prefetch reads NNF_G floats past
 // j1; every cloud allocation carries that much slack.
-template <int Q>
+template <int Q, bool PERM>
 __device__ __forceinline__ void scan_range(const float* __restrict__ txp, const float* __restrict__ typ,
-                                           const float* __restrict__ tzp, int j0, int j1, const float (&qx)[Q],
+                                           const float* __restrict__ tzp, const int* __restrict__ tperm, int j0,
+                                           int j1, const float (&qx)[Q],
                                            const float (&qy)[Q], const float (&qz)[Q], float (&bd)[Q], int (&bj)[Q],
                                            float (&T)[Q]) {
   float XA[NNF_G], YA[NNF_G], ZA[NNF_G], XB[NNF_G], YB[NNF_G], ZB[NNF_G];
@@ -231,7 +234,7 @@ __device__ __forceinline__ void scan_range(const float* __restrict__ txp, const 
     hit = false;
 #pragma unroll
     for (int u = 0; u < Q; ++u) hit |= (m[u] <= T[u]);
-    if (__builtin_amdgcn_ballot_w64(hit) != 0) group_exact<Q>(qx, qy, qz, XA, YA, ZA, e, j, bd, bj, T);
+    if (__builtin_amdgcn_ballot_w64(hit) != 0) group_exact<Q, PERM>(qx, qy, qz, XA, YA, ZA, e, j, tperm, bd, bj, T);
 #pragma unroll
     for (int k = 0; k < NNF_G; ++k) {
       XA[k] = txp[j + 2 * NNF_G + k];
@@ -242,7 +245,8 @@ __device__ __forceinline__ void scan_range(const float* __restrict__ txp, const 
     hit = false;
 #pragma unroll
     for (int u = 0; u < Q; ++u) hit |= (m[u] <= T[u]);
-    if (__builtin_amdgcn_ballot_w64(hit) != 0) group_exact<Q>(qx, qy, qz, XB, YB, ZB, e, j + NNF_G, bd, bj, T);
+    if (__builtin_amdgcn_ballot_w64(hit) != 0)
+      group_exact<Q, PERM>(qx, qy, qz, XB, YB, ZB, e, j + NNF_G, tperm, bd, bj, T);
   }
 }
 
@@ -276,24 +280,32 @@ __global__ __launch_bounds__(NN_THREADS) void nn_filtered_kernel(
     const float* __restrict__ qxp, const float* __restrict__ qyp, const float* __restrict__ qzp, int nq,
     const float* __restrict__ txp, const float* __restrict__ typ, const float* __restrict__ tzp, int nt_pad,
     int tiles_per_chunk, const nn_key_t* __restrict__ seed, int seed_scale, nn_key_t* __restrict__ best,
-    const float* __restrict__ tbox, int tbox_stride, const float* __restrict__ sbox, int sbox_stride) {
+    const float* __restrict__ tbox, int tbox_stride, const float* __restrict__ sbox, int sbox_stride,
+    const float* __restrict__ oxp, const float* __restrict__ oyp, const float* __restrict__ ozp,
+    const int* __restrict__ tperm, const int* __restrict__ qperm) {
+  // PRUNE: txp/typ/tzp are the Morton-ordered target planes, oxp/oyp/ozp the caller's
+  // order (seeds index those), tperm maps scanned position -> original index and
+  // qperm lists the queries in Morton order (so a wave holds a compact cluster).
+  // !PRUNE: oxp == txp, no permutations.
   const int tid = threadIdx.x;
   const int ibase = blockIdx.x * (NN_THREADS * Q) + tid;
   float qx[Q], qy[Q], qz[Q], bd[Q], T[Q];
-  int bj[Q];
+  int bj[Q], qi[Q];
   nn_key_t key0[Q];
 #pragma unroll
   for (int u = 0; u < Q; ++u) {
-    const int i = ibase + u * NN_THREADS;
-    const bool live = i < nq;
+    const int ip = ibase + u * NN_THREADS;
+    const bool live = ip < nq;
+    const int i = live ? (PRUNE ? qperm[ip] : ip) : 0;
+    qi[u] = live ? i : -1;
     qx[u] = live ? qxp[i] : 0.f;
     qy[u] = live ? qyp[i] : 0.f;
     qz[u] = live ? qzp[i] : 0.f;
     int js = live ? (int)(unsigned)(seed[i] & 0xffffffffu) * seed_scale : 0;
-    float ds = pair_dist(qx[u], qy[u], qz[u], txp[js], typ[js], tzp[js]);
+    float ds = pair_dist(qx[u], qy[u], qz[u], oxp[js], oyp[js], ozp[js]);
     if (!(ds <= 3.402823466e38f)) {  // inf/NaN: fall back to the reference's literal seed, element 0
       js = 0;
-      ds = pair_dist(qx[u], qy[u], qz[u], txp[0], typ[0], tzp[0]);
+      ds = pair_dist(qx[u], qy[u], qz[u], oxp[0], oyp[0], ozp[0]);
     }
     bd[u] = ds;
     bj[u] = js;
@@ -307,7 +319,7 @@ __global__ __launch_bounds__(NN_THREADS) void nn_filtered_kernel(
   if (tile1 > ntiles) tile1 = ntiles;
 
   if (!PRUNE) {
-    scan_range<Q>(txp, typ, tzp, tile0 * NN_TILE, tile1 * NN_TILE, qx, qy, qz, bd, bj, T);
+    scan_range<Q, false>(txp, typ, tzp, nullptr, tile0 * NN_TILE, tile1 * NN_TILE, qx, qy, qz, bd, bj, T);
   } else {
     for (int t = tile0; t < tile1; ++t) {
       const bool th = box_may_hit<Q>(qx, qy, qz, tbox[t], tbox[tbox_stride + t], tbox[2 * tbox_stride + t],
@@ -321,7 +333,7 @@ __global__ __launch_bounds__(NN_THREADS) void nn_filtered_kernel(
                                        sbox[5 * sbox_stride + sb], T);
         if (__builtin_amdgcn_ballot_w64(sh) != 0) {
           const int js = sb * NN_SUB;
-          scan_range<Q>(txp, typ, tzp, js, js + NN_SUB, qx, qy, qz, bd, bj, T);
+          scan_range<Q, true>(txp, typ, tzp, tperm, js, js + NN_SUB, qx, qy, qz, bd, bj, T);
         }
       }
     }
@@ -329,11 +341,10 @@ __global__ __launch_bounds__(NN_THREADS) void nn_filtered_kernel(
 
 #pragma unroll
   for (int u = 0; u < Q; ++u) {
-    const int i = ibase + u * NN_THREADS;
     const nn_key_t key = ((nn_key_t)__float_as_uint(bd[u]) << 32) | (nn_key_t)(unsigned)bj[u];
     // chunk 0 always publishes (so the seed candidate itself is in the result);
     // the others only if they improved on it
-    if (i < nq && (blockIdx.y == 0 || key < key0[u])) atomicMin(&best[i], key);
+    if (qi[u] >= 0 && (blockIdx.y == 0 || key < key0[u])) atomicMin(&best[qi[u]], key);
   }
 }
 
@@ -346,7 +357,9 @@ void launch_nn_filtered(const NnArgs& a, const nn_key_t* seed, int seed_scale, i
 #define ICPK_LAUNCH(Q, P)                                                                                           \
   hipLaunchKernelGGL((nn_filtered_kernel<Q, P>), grid, dim3(NN_THREADS), 0, s, a.qx, a.qy, a.qz, a.nq, a.tx, a.ty,   \
                      a.tz, a.nt_pad, a.tiles_per_chunk, seed, seed_scale, a.best, boxes ? boxes->tbox : nullptr,     \
-                     boxes ? boxes->tbox_stride : 0, boxes ? boxes->sbox : nullptr, boxes ? boxes->sbox_stride : 0)
+                     boxes ? boxes->tbox_stride : 0, boxes ? boxes->sbox : nullptr, boxes ? boxes->sbox_stride : 0,     \
+                     boxes ? boxes->ox : a.tx, boxes ? boxes->oy : a.ty, boxes ? boxes->oz : a.tz,                    \
+                     boxes ? boxes->tperm : nullptr, boxes ? boxes->qperm : nullptr)
   if (boxes) {
     if (q == 2) ICPK_LAUNCH(2, true); else ICPK_LAUNCH(1, true);
   } else {

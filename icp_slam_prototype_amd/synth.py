@@ -108,7 +108,7 @@ def kinect_pair(rows=480, cols=640, valid=0.30, seed=2, rot_deg=(0.0, 2.0, 0.0),
         src = src + CAMERA_START
     return dict(source=src.astype(np.float32), target=tgt.astype(np.float32),
                 depth_src=depth_s, depth_tgt=depth_t, R_true=Rm,
-                t_true=np.asarray(shift, np.float64))
+                t_true=np.asarray(shift, np.float64), fx=float(fx), cx=float(cx))
 
 
 def frustum_pair(n=10000, seed=1, rot_deg=(0.0, 5.0, 0.0), shift=(0.02, -0.01, 0.03)):
