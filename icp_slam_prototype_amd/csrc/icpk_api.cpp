@@ -50,6 +50,7 @@ struct icpk_ctx {
   // pruned scan: Morton-ordered copy of the target, its permutation, the query order
   Cloud sorted;
   int* tperm = nullptr;
+  unsigned* tkeys = nullptr;  // sorted Morton codes of the target (first-sweep seeding)
   int tperm_cap = 0;
   int* qperm = nullptr;
   int qperm_cap = 0;
@@ -251,6 +252,9 @@ int prepare_pruned_target(icpk_ctx* ctx, NnBoxes& bx) {
     ctx->tperm = nullptr;
     ctx->tperm_cap = 0;
     ICPK_HIP(ctx, hipMalloc((void**)&ctx->tperm, ((size_t)nt_pad + 64) * sizeof(int)));
+    if (ctx->tkeys) ICPK_HIP(ctx, hipFree(ctx->tkeys));
+    ctx->tkeys = nullptr;
+    ICPK_HIP(ctx, hipMalloc((void**)&ctx->tkeys, ((size_t)nt_pad + 64) * sizeof(unsigned)));
     ctx->tperm_cap = nt_pad;
     ctx->have_boxes = false;
   }
@@ -273,6 +277,8 @@ int prepare_pruned_target(icpk_ctx* ctx, NnBoxes& bx) {
   launch_bounds(bx.tbox, bx.tbox_stride, ntiles, ctx->bounds, ctx->stream);
   rc = enqueue_morton_order(ctx, ctx->tgt, ctx->tperm);
   if (rc) return rc;
+  ICPK_HIP(ctx, hipMemcpyAsync(ctx->tkeys, ctx->sort_keys + ctx->sort_cap, (size_t)nt * sizeof(unsigned),
+                               hipMemcpyDeviceToDevice, ctx->stream));
   launch_gather_planes(ctx->tgt.x(), ctx->tgt.y(), ctx->tgt.z(), ctx->tperm, nt, nt_pad, __builtin_inff(),
                        ctx->sorted.x(), ctx->sorted.y(), ctx->sorted.z(), ctx->tperm, ctx->stream);
   launch_tile_boxes(ctx->sorted.x(), ctx->sorted.y(), ctx->sorted.z(), nt, ntiles, bx, ctx->stream);
@@ -313,6 +319,38 @@ int enqueue_nn(icpk_ctx* ctx, int nn_mode) {
     a.best = ctx->best;
     launch_fill_u64(ctx->best, nq, NN_KEY_INIT, ctx->stream);
     launch_nn_exact(a, ctx->stream);
+  } else if (nn_mode == ICPK_NN_PRUNED) {
+    if (round_up(nq, NN_TILE) > ctx->qperm_cap) {
+      if (ctx->qperm) ICPK_HIP(ctx, hipFree(ctx->qperm));
+      ctx->qperm = nullptr;
+      ctx->qperm_cap = 0;
+      ICPK_HIP(ctx, hipMalloc((void**)&ctx->qperm, (size_t)round_up(nq, NN_TILE) * sizeof(int)));
+      ctx->qperm_cap = round_up(nq, NN_TILE);
+      ctx->have_qperm = false;
+    }
+    NnBoxes bx;
+    rc = prepare_pruned_target(ctx, bx);
+    if (rc) return rc;
+    if (!ctx->have_qperm || !ctx->have_seed) {
+      // query order = Morton order of the source at its current pose (once per alignment);
+      // the unsorted query keys stay in sort_keys[0..nq)
+      rc = enqueue_morton_order(ctx, ctx->src, ctx->qperm);
+      if (rc) return rc;
+      ctx->have_qperm = true;
+    }
+    if (ctx->have_seed) {  // matches of the previous sweep seed this one
+      nn_key_t* t = ctx->seed;
+      ctx->seed = ctx->best;
+      ctx->best = t;
+    } else {  // first sweep: the target with the nearest Morton code
+      launch_seed_morton(ctx->sort_keys, nq, ctx->tkeys, ctx->tperm, ctx->tgt.n, ctx->seed, ctx->stream);
+    }
+    a.tx = ctx->sorted.x();
+    a.ty = ctx->sorted.y();
+    a.tz = ctx->sorted.z();
+    a.tiles_per_chunk = ntiles;
+    a.best = ctx->best;
+    launch_nn_pruned(a, ctx->seed, 1, bx, ctx->stream);
   } else {
     int seed_scale = 1;
     if (ctx->have_seed) {
@@ -341,34 +379,11 @@ int enqueue_nn(icpk_ctx* ctx, int nn_mode) {
       launch_nn_exact(c, ctx->stream);
       seed_scale = NN_SEED_STRIDE;
     }
-    NnBoxes bx;
-    const NnBoxes* pbx = nullptr;
-    if (nn_mode == ICPK_NN_PRUNED) {
-      if (round_up(nq, NN_TILE) > ctx->qperm_cap) {
-        if (ctx->qperm) ICPK_HIP(ctx, hipFree(ctx->qperm));
-        ctx->qperm = nullptr;
-        ctx->qperm_cap = 0;
-        ICPK_HIP(ctx, hipMalloc((void**)&ctx->qperm, (size_t)round_up(nq, NN_TILE) * sizeof(int)));
-        ctx->qperm_cap = round_up(nq, NN_TILE);
-        ctx->have_qperm = false;
-      }
-      rc = prepare_pruned_target(ctx, bx);
-      if (rc) return rc;
-      if (!ctx->have_qperm) {  // query order: Morton order of the source at its current pose
-        rc = enqueue_morton_order(ctx, ctx->src, ctx->qperm);
-        if (rc) return rc;
-        ctx->have_qperm = true;
-      }
-      a.tx = ctx->sorted.x();
-      a.ty = ctx->sorted.y();
-      a.tz = ctx->sorted.z();
-      pbx = &bx;
-    }
     const int q = ctx->q_per_lane > 0 ? ctx->q_per_lane : (nq >= 65536 ? 2 : 1);
     a.tiles_per_chunk = chunking((nq + NN_THREADS * q - 1) / (NN_THREADS * q), ntiles);
     a.best = ctx->best;
     launch_fill_u64(ctx->best, nq, NN_KEY_INIT, ctx->stream);
-    launch_nn_filtered(a, ctx->seed, seed_scale, q, pbx, ctx->stream);
+    launch_nn_filtered(a, ctx->seed, seed_scale, q, nullptr, ctx->stream);
   }
   ICPK_HIP(ctx, hipGetLastError());
   ctx->have_assoc = true;
@@ -460,7 +475,7 @@ void icpk_destroy(icpk_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   for (hipEvent_t e : ctx->events) (void)hipEventDestroy(e);
-  void* dev[] = {ctx->sorted.base, ctx->tperm, ctx->qperm, ctx->bounds, ctx->sort_keys, ctx->sort_vals, ctx->sort_temp,
+  void* dev[] = {ctx->sorted.base, ctx->tkeys, ctx->tperm, ctx->qperm, ctx->bounds, ctx->sort_keys, ctx->sort_vals, ctx->sort_temp,
                  ctx->nrm.base, ctx->boxes, ctx->dec.base, ctx->tgt.base, ctx->src0.base, ctx->src.base, ctx->best,      ctx->seed,     ctx->idx,
                  ctx->dist,     ctx->partial,   ctx->pcount,   ctx->red_out,   ctx->depth_dev, ctx->bp_counts};
   for (void* p : dev)

@@ -85,6 +85,10 @@ void launch_gather_planes(const float* x, const float* y, const float* z, const 
 // boxes == nullptr: brute force over every target
 void launch_nn_filtered(const NnArgs& a, const nn_key_t* seed, int seed_scale, int q_per_lane, const NnBoxes* boxes,
                         hipStream_t s);
+// kernels_nn_pruned.hip
+void launch_nn_pruned(const NnArgs& a, const nn_key_t* seed, int seed_scale, const NnBoxes& b, hipStream_t s);
+void launch_seed_morton(const unsigned* qkeys, int nq, const unsigned* tkeys, const int* tperm, int nt, nn_key_t* seed,
+                        hipStream_t s);
 void launch_tile_boxes(const float* x, const float* y, const float* z, int n, int ntiles, const NnBoxes& b,
                        hipStream_t s);
 void launch_decimate(const float* x, const float* y, const float* z, int n, int stride, float* ox, float* oy, float* oz,
