@@ -47,6 +47,7 @@ class Params(C.Structure):
         ("profile", C.c_int32),
         ("last_rotation", C.c_float * 9),
         ("last_translation", C.c_float * 3),
+        ("host_loop", C.c_int32),
     ]
 
 

@@ -16,7 +16,7 @@
 
 #include "icpk.h"
 #include "icpk_internal.h"
-#include "solve.h"
+#include "solve_impl.h"
 
 using namespace icpk;
 
@@ -71,6 +71,10 @@ struct icpk_ctx {
   int* pcount = nullptr;
   double* red_out = nullptr;   // device, 20 x 8 bytes
   double* red_host = nullptr;  // pinned, 20 x 8 bytes
+  LoopState* st_dev = nullptr;   // device-side loop state
+  LoopState* st_host = nullptr;  // pinned staging copy
+  const int* stop = nullptr;     // &st_dev->done while a device loop is being enqueued, else null
+  LoopState* st_active = nullptr;  // st_dev while a device loop is being enqueued, else null
   uint16_t* depth_dev = nullptr;
   int depth_cap = 0;
   int* bp_counts = nullptr;
@@ -313,11 +317,12 @@ int enqueue_nn(icpk_ctx* ctx, int nn_mode) {
   a.ty = ctx->tgt.y();
   a.tz = ctx->tgt.z();
   a.nt_pad = round_up(ctx->tgt.n, NN_TILE);
+  a.stop = ctx->stop;
   const int ntiles = a.nt_pad / NN_TILE;
   if (nn_mode == ICPK_NN_EXACT) {
     a.tiles_per_chunk = chunking((nq + NN_THREADS - 1) / NN_THREADS, ntiles);
     a.best = ctx->best;
-    launch_fill_u64(ctx->best, nq, NN_KEY_INIT, ctx->stream);
+    launch_fill_u64(ctx->best, nq, NN_KEY_INIT, ctx->stop, ctx->stream);
     launch_nn_exact(a, ctx->stream);
   } else if (nn_mode == ICPK_NN_PRUNED) {
     if (round_up(nq, NN_TILE) > ctx->qperm_cap) {
@@ -375,14 +380,14 @@ int enqueue_nn(icpk_ctx* ctx, int nn_mode) {
       c.nt_pad = round_up(ctx->dec.n, NN_TILE);
       c.tiles_per_chunk = chunking((nq + NN_THREADS - 1) / NN_THREADS, c.nt_pad / NN_TILE);
       c.best = ctx->seed;
-      launch_fill_u64(ctx->seed, nq, NN_KEY_INIT, ctx->stream);
+      launch_fill_u64(ctx->seed, nq, NN_KEY_INIT, ctx->stop, ctx->stream);
       launch_nn_exact(c, ctx->stream);
       seed_scale = NN_SEED_STRIDE;
     }
     const int q = ctx->q_per_lane > 0 ? ctx->q_per_lane : (nq >= 65536 ? 2 : 1);
     a.tiles_per_chunk = chunking((nq + NN_THREADS * q - 1) / (NN_THREADS * q), ntiles);
     a.best = ctx->best;
-    launch_fill_u64(ctx->best, nq, NN_KEY_INIT, ctx->stream);
+    launch_fill_u64(ctx->best, nq, NN_KEY_INIT, ctx->stop, ctx->stream);
     launch_nn_filtered(a, ctx->seed, seed_scale, q, nullptr, ctx->stream);
   }
   ICPK_HIP(ctx, hipGetLastError());
@@ -395,10 +400,12 @@ int enqueue_nn(icpk_ctx* ctx, int nn_mode) {
 int enqueue_reduce(icpk_ctx* ctx, float max_dist) {
   const int nq = ctx->src.n;
   launch_assoc_reduce(ctx->best, ctx->src.x(), ctx->src.y(), ctx->src.z(), nq, ctx->tgt.x(), ctx->tgt.y(), ctx->tgt.z(),
-                      max_dist, ctx->idx, ctx->dist, ctx->partial, ctx->pcount, ctx->red_out, ctx->stream);
+                      max_dist, ctx->idx, ctx->dist, ctx->partial, ctx->pcount, ctx->st_active ? nullptr : ctx->red_out,
+                      ctx->st_active, ctx->stream);
   ICPK_HIP(ctx, hipGetLastError());
-  ICPK_HIP(ctx, hipMemcpyAsync(ctx->red_host, ctx->red_out, (NSUM + 1) * sizeof(double), hipMemcpyDeviceToHost,
-                               ctx->stream));
+  if (!ctx->st_active)
+    ICPK_HIP(ctx, hipMemcpyAsync(ctx->red_host, ctx->red_out, (NSUM + 1) * sizeof(double), hipMemcpyDeviceToHost,
+                                 ctx->stream));
   return ICPK_OK;
 }
 
@@ -406,10 +413,11 @@ int enqueue_reduce(icpk_ctx* ctx, float max_dist) {
 int enqueue_reduce_p2l(icpk_ctx* ctx, float max_dist) {
   launch_p2l_reduce(ctx->best, ctx->src.x(), ctx->src.y(), ctx->src.z(), ctx->src.n, ctx->tgt.x(), ctx->tgt.y(),
                     ctx->tgt.z(), ctx->nrm.x(), ctx->nrm.y(), ctx->nrm.z(), max_dist, ctx->idx, ctx->dist, ctx->partial,
-                    ctx->pcount, ctx->red_out, ctx->stream);
+                    ctx->pcount, ctx->st_active ? nullptr : ctx->red_out, ctx->st_active, ctx->stream);
   ICPK_HIP(ctx, hipGetLastError());
-  ICPK_HIP(ctx, hipMemcpyAsync(ctx->red_host, ctx->red_out, (NP2L + 1) * sizeof(double), hipMemcpyDeviceToHost,
-                               ctx->stream));
+  if (!ctx->st_active)
+    ICPK_HIP(ctx, hipMemcpyAsync(ctx->red_host, ctx->red_out, (NP2L + 1) * sizeof(double), hipMemcpyDeviceToHost,
+                                 ctx->stream));
   return ICPK_OK;
 }
 
@@ -453,6 +461,8 @@ int icpk_create(icpk_ctx** out, int device_id) {
   ok = ok && hipMalloc((void**)&ctx->red_out, (NSUM_MAX + 1) * sizeof(double)) == hipSuccess;
   ok = ok && hipHostMalloc((void**)&ctx->red_host, (NSUM_MAX + 1) * sizeof(double), hipHostMallocDefault) == hipSuccess;
   ok = ok && hipHostMalloc((void**)&ctx->bp_n_host, sizeof(int), hipHostMallocDefault) == hipSuccess;
+  ok = ok && hipMalloc((void**)&ctx->st_dev, sizeof(LoopState)) == hipSuccess;
+  ok = ok && hipHostMalloc((void**)&ctx->st_host, sizeof(LoopState), hipHostMallocDefault) == hipSuccess;
   if (!ok) {
     icpk_destroy(ctx);
     return ICPK_E_HIP;
@@ -475,13 +485,14 @@ void icpk_destroy(icpk_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   for (hipEvent_t e : ctx->events) (void)hipEventDestroy(e);
-  void* dev[] = {ctx->sorted.base, ctx->tkeys, ctx->tperm, ctx->qperm, ctx->bounds, ctx->sort_keys, ctx->sort_vals, ctx->sort_temp,
+  void* dev[] = {ctx->st_dev, ctx->sorted.base, ctx->tkeys, ctx->tperm, ctx->qperm, ctx->bounds, ctx->sort_keys, ctx->sort_vals, ctx->sort_temp,
                  ctx->nrm.base, ctx->boxes, ctx->dec.base, ctx->tgt.base, ctx->src0.base, ctx->src.base, ctx->best,      ctx->seed,     ctx->idx,
                  ctx->dist,     ctx->partial,   ctx->pcount,   ctx->red_out,   ctx->depth_dev, ctx->bp_counts};
   for (void* p : dev)
     if (p) (void)hipFree(p);
   if (ctx->red_host) (void)hipHostFree(ctx->red_host);
   if (ctx->bp_n_host) (void)hipHostFree(ctx->bp_n_host);
+  if (ctx->st_host) (void)hipHostFree(ctx->st_host);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -657,6 +668,121 @@ int icpk_transform_source(icpk_ctx* ctx, const float R[9], const float t[3]) {
   return ICPK_OK;
 }
 
+// Whole alignment enqueued up front; loop test, solve and pose accumulation run on the
+// device (kernels_loop.hip).  Same results as the host loop below.
+static int align_device_loop(icpk_ctx* ctx, const icpk_params* p, float T_out[16], icpk_stats* stats) {
+  const bool prof = p->profile != 0;
+  const bool p2l = p->solve == ICPK_SOLVE_POINT_TO_PLANE;
+  const int nsum = p2l ? NP2L : NSUM;
+  const int B = red_blocks(ctx->src.n);
+  size_t nev = 0;
+  std::vector<size_t> ev_nn, ev_red, ev_tr;
+  auto stamp = [&](std::vector<size_t>* list) -> int {
+    if (!prof) return ICPK_OK;
+    hipEvent_t e = get_event(ctx, nev);
+    if (!e) return fail(ctx, ICPK_E_HIP, "hipEventCreate failed");
+    ICPK_HIP(ctx, hipEventRecord(e, ctx->stream));
+    if (list) list->push_back(nev);
+    ++nev;
+    return ICPK_OK;
+  };
+  LoopState* h = ctx->st_host;
+  std::memset(h, 0, offsetof(LoopState, trace_R));
+  h->Trot[0] = h->Trot[4] = h->Trot[8] = 1.f;
+  h->Tk[0] = h->Tk[5] = h->Tk[10] = 1.0;
+  h->max_iterations = p->max_iterations;
+  h->min_pairs = p->min_pairs;
+  h->solve = p->solve;
+  h->fixed_iterations = p->fixed_iterations;
+  h->threshold = p->threshold;
+  std::memcpy(h->last_rotation, p->last_rotation, sizeof(h->last_rotation));
+  std::memcpy(h->last_translation, p->last_translation, sizeof(h->last_translation));
+  ICPK_HIP(ctx, hipMemcpyAsync(ctx->st_dev, h, offsetof(LoopState, trace_R), hipMemcpyHostToDevice, ctx->stream));
+
+  struct Guard {  // the stop flags are only meaningful while this alignment is being enqueued
+    icpk_ctx* c;
+    ~Guard() {
+      c->stop = nullptr;
+      c->st_active = nullptr;
+    }
+  } guard{ctx};
+  ctx->stop = &ctx->st_dev->done;
+  ctx->st_active = ctx->st_dev;
+
+  std::vector<nn_key_t*> best_of_sweep;
+  auto sweep = [&]() -> int {
+    int r = stamp(&ev_nn);
+    if (r) return r;
+    r = enqueue_nn(ctx, p->nn_mode);
+    if (r) return r;
+    best_of_sweep.push_back(ctx->best);
+    r = stamp(&ev_red);
+    if (r) return r;
+    r = p2l ? enqueue_reduce_p2l(ctx, p->max_nn_dist) : enqueue_reduce(ctx, p->max_nn_dist);
+    if (r) return r;
+    return stamp(nullptr);
+  };
+  int rc = sweep();  // icp.cpp:98
+  if (rc) return rc;
+  for (int i = 0; i < p->max_iterations; ++i) {
+    launch_loop_step(ctx->partial, ctx->pcount, B, nsum, ctx->st_dev, 0, ctx->stream);
+    rc = stamp(&ev_tr);
+    if (rc) return rc;
+    launch_transform_state(ctx->src.x(), ctx->src.y(), ctx->src.z(), ctx->src.n, ctx->st_dev, ctx->stream);
+    rc = stamp(nullptr);
+    if (rc) return rc;
+    rc = sweep();  // icp.cpp:255
+    if (rc) return rc;
+  }
+  launch_loop_step(ctx->partial, ctx->pcount, B, nsum, ctx->st_dev, 1, ctx->stream);
+  ICPK_HIP(ctx, hipGetLastError());
+  ICPK_HIP(ctx, hipMemcpyAsync(h, ctx->st_dev, sizeof(LoopState), hipMemcpyDeviceToHost, ctx->stream));
+  ICPK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+
+  // the associations of the last EXECUTED sweep are the result
+  const int k = h->sweeps;
+  if (k >= 1 && k <= (int)best_of_sweep.size()) {
+    nn_key_t* fin = best_of_sweep[k - 1];
+    if (fin != ctx->best) {
+      ctx->seed = ctx->best;
+      ctx->best = fin;
+    }
+  }
+  const int it = h->iterations;
+  if (p->solve == ICPK_SOLVE_REFERENCE) {
+    for (int r = 0; r < 3; ++r) {
+      for (int c = 0; c < 3; ++c) T_out[4 * r + c] = h->Trot[3 * r + c];
+      T_out[4 * r + 3] = h->offset[r];  // icp.cpp:266-268
+    }
+  } else {
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 4; ++c) T_out[4 * r + c] = (float)h->Tk[4 * r + c];
+  }
+  ctx->trace_R.assign(h->trace_R, h->trace_R + 9 * it);
+  ctx->trace_t.assign(h->trace_t, h->trace_t + 3 * it);
+  ctx->trace_mse.assign(h->trace_mse, h->trace_mse + it);
+  ctx->trace_pairs.assign(h->trace_pairs, h->trace_pairs + it);
+  if (stats) {
+    stats->iterations = it;
+    stats->status = h->status;
+    stats->final_pairs = (int32_t)h->pairs;
+    stats->final_mse = h->mse;
+    stats->nn_launches = k;
+    if (prof && nev >= 2) {
+      auto span = [&](size_t a, size_t b) {
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, ctx->events[a], ctx->events[b]);
+        return ms;
+      };
+      for (size_t e : ev_nn) stats->nn_ms_total += span(e, e + 1);
+      for (size_t e : ev_red) stats->reduce_ms_total += span(e, e + 1);
+      for (size_t e : ev_tr) stats->transform_ms_total += span(e, e + 1);
+      stats->total_ms = span(0, nev - 1);
+    }
+  }
+  return h->status;
+}
+
 int icpk_transform_target(icpk_ctx* ctx, const float R[9], const float t[3]) {
   if (!ctx || !R || !t) return ICPK_E_ARG;
   if (!ctx->have_tgt) return fail(ctx, ICPK_E_NOT_SET, "target cloud not set");
@@ -715,6 +841,12 @@ int icpk_align(icpk_ctx* ctx, const icpk_params* p, float T_out[16], icpk_stats*
   if (rc) return rc;
   ctx->have_seed = false;  // matches of an earlier alignment belong to a different source pose
   ctx->have_qperm = false;
+  ctx->trace_R.clear();
+  ctx->trace_t.clear();
+  ctx->trace_mse.clear();
+  ctx->trace_pairs.clear();
+  if (!p->host_loop && !ctx->log_fn && ctx->src.n > 0 && p->max_iterations <= LOOP_MAX_ITER)
+    return align_device_loop(ctx, p, T_out, stats);
 
   const bool prof = p->profile != 0;
   size_t nev = 0;

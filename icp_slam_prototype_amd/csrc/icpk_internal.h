@@ -31,6 +31,7 @@ struct NnArgs {
   int nt_pad;           // multiple of NN_TILE
   int tiles_per_chunk;  // target tiles handled by one workgroup
   nn_key_t* best;       // [nq], pre-set to NN_KEY_INIT
+  const int* stop;      // device-loop stop flags (LoopState), or nullptr
 };
 
 struct Rt {
@@ -52,7 +53,7 @@ inline int red_blocks(int n) {
 }
 
 // kernels_nn.hip
-void launch_fill_u64(nn_key_t* p, int n, nn_key_t v, hipStream_t s);
+void launch_fill_u64(nn_key_t* p, int n, nn_key_t v, const int* stop, hipStream_t s);
 void launch_nn_exact(const NnArgs& a, hipStream_t s);
 // bounding boxes for the pruned scan: 6 planes (lo x,y,z, hi x,y,z) per 1024-target
 // tile (tbox) and per 128-target sub-tile (sbox)
@@ -96,17 +97,59 @@ void launch_decimate(const float* x, const float* y, const float* z, int n, int 
 constexpr int NN_SEED_STRIDE = 16;  // decimation of the target for the seeding pre-pass
 void launch_pair_distance(const float* a, const float* b, float* out, int n, hipStream_t s);
 
+// ---- device-side ICP loop (kernels_loop.hip) ------------------------------------
+// One LoopState per context lives in device memory; while an alignment runs, every
+// kernel of every iteration is enqueued up front and consults it: once `done` (or
+// `stop_after_transform`) is set the remaining launches are no-ops, so no host
+// round trip is needed to decide the loop exit of icp.cpp:155.
+constexpr int LOOP_MAX_ITER = 256;
+struct LoopState {
+  int done;                  // loop exited (threshold met / max iterations / degenerate)
+  int stop_after_transform;  // < min_pairs fallback (icp.cpp:163-182): apply rt, then stop
+  int iterations;            // completed loop bodies
+  int status;
+  int sweeps;                // NN sweeps executed (tells the host which buffer holds the result)
+  int pad0;
+  long long pairs;           // associations of the latest sweep
+  float mse;                 // icp.cpp:622-638 of the latest sweep
+  float pad1;
+  Rt rt;                     // transform to apply in this iteration
+  float Trot[9];             // icp.cpp:227-233
+  float offset[3];           // icp.cpp:240
+  double Tk[12];             // accumulated [R|t] (Kabsch / point-to-plane)
+  // parameters
+  int max_iterations, min_pairs, solve, fixed_iterations;
+  float threshold;
+  float last_rotation[9], last_translation[3];
+  // per-iteration record (icpk_get_trace)
+  float trace_R[LOOP_MAX_ITER * 9];
+  float trace_t[LOOP_MAX_ITER * 3];
+  float trace_mse[LOOP_MAX_ITER];
+  int trace_pairs[LOOP_MAX_ITER];
+};
+// the first two ints of LoopState, as seen by kernels that only need to know whether to run
+__device__ __forceinline__ bool loop_stopped(const int* stop) { return stop && (stop[0] | stop[1]); }
+
+// sums the per-block partials with the canonical tree and, unless stats_only, performs
+// one loop body's host work on the device: exit test, solve, pose accumulation, trace
+void launch_loop_step(const double* partial, const int* pcount, int nblocks, int nsum, LoopState* st, int stats_only,
+                      hipStream_t s);
+void launch_transform_state(float* x, float* y, float* z, int n, const LoopState* st, hipStream_t s);
+void launch_reduce_final(const double* partial, const int* pcount, int nblocks, int nsum, double* out, hipStream_t s);
+
 // kernels_reduce.hip
 // partial: [RED_MAX_BLOCKS][NSUM_MAX] doubles, pcount: [RED_MAX_BLOCKS] ints,
 // out: nsum doubles followed by one int64 count ((NSUM_MAX + 1) x 8 bytes).
+// out == nullptr: only the per-block partials are produced (the device loop sums them
+// in launch_loop_step); stop: device-loop stop flags or nullptr
 void launch_assoc_reduce(const nn_key_t* best, const float* ax, const float* ay, const float* az, int nq,
                          const float* tx, const float* ty, const float* tz, float max_dist, int32_t* idx_out,
-                         float* dist_out, double* partial, int* pcount, double* out, hipStream_t s);
+                         float* dist_out, double* partial, int* pcount, double* out, LoopState* st, hipStream_t s);
 
 void launch_p2l_reduce(const nn_key_t* best, const float* ax, const float* ay, const float* az, int nq, const float* tx,
                        const float* ty, const float* tz, const float* nx, const float* ny, const float* nz,
                        float max_dist, int32_t* idx_out, float* dist_out, double* partial, int* pcount, double* out,
-                       hipStream_t s);
+                       LoopState* st, hipStream_t s);
 
 // kernels_transform.hip
 void launch_transform(float* x, float* y, float* z, int n, const Rt& rt, hipStream_t s);

@@ -19,20 +19,22 @@
 
 namespace icpk {
 
-__global__ void fill_u64_kernel(nn_key_t* __restrict__ p, int n, nn_key_t v) {
+__global__ void fill_u64_kernel(nn_key_t* __restrict__ p, int n, nn_key_t v, const int* __restrict__ stop) {
+  if (loop_stopped(stop)) return;
   const int stride = gridDim.x * blockDim.x;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = v;
 }
 
-void launch_fill_u64(nn_key_t* p, int n, nn_key_t v, hipStream_t s) {
+void launch_fill_u64(nn_key_t* p, int n, nn_key_t v, const int* stop, hipStream_t s) {
   if (n <= 0) return;
   int blocks = (n + 255) / 256;
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(fill_u64_kernel, dim3(blocks), dim3(256), 0, s, p, n, v);
+  hipLaunchKernelGGL(fill_u64_kernel, dim3(blocks), dim3(256), 0, s, p, n, v, stop);
 }
 
 // ---- K1 exact -----------------------------------------------------------------
 __global__ __launch_bounds__(NN_THREADS) void nn_exact_kernel(NnArgs a) {
+  if (loop_stopped(a.stop)) return;
   __shared__ float4 sx[NN_TILE / 4];
   __shared__ float4 sy[NN_TILE / 4];
   __shared__ float4 sz[NN_TILE / 4];
@@ -190,7 +192,8 @@ __global__ __launch_bounds__(NN_THREADS) void nn_filtered_kernel(
     int tiles_per_chunk, const nn_key_t* __restrict__ seed, int seed_scale, nn_key_t* __restrict__ best,
     const float* __restrict__ tbox, int tbox_stride, const float* __restrict__ sbox, int sbox_stride,
     const float* __restrict__ oxp, const float* __restrict__ oyp, const float* __restrict__ ozp,
-    const int* __restrict__ tperm, const int* __restrict__ qperm) {
+    const int* __restrict__ tperm, const int* __restrict__ qperm, const int* __restrict__ stop) {
+  if (loop_stopped(stop)) return;
   // PRUNE: txp/typ/tzp are the Morton-ordered target planes, oxp/oyp/ozp the caller's
   // order (seeds index those), tperm maps scanned position -> original index and
   // qperm lists the queries in Morton order (so a wave holds a compact cluster).
@@ -267,7 +270,7 @@ void launch_nn_filtered(const NnArgs& a, const nn_key_t* seed, int seed_scale, i
                      a.tz, a.nt_pad, a.tiles_per_chunk, seed, seed_scale, a.best, boxes ? boxes->tbox : nullptr,     \
                      boxes ? boxes->tbox_stride : 0, boxes ? boxes->sbox : nullptr, boxes ? boxes->sbox_stride : 0,     \
                      boxes ? boxes->ox : a.tx, boxes ? boxes->oy : a.ty, boxes ? boxes->oz : a.tz,                    \
-                     boxes ? boxes->tperm : nullptr, boxes ? boxes->qperm : nullptr)
+                     boxes ? boxes->tperm : nullptr, boxes ? boxes->qperm : nullptr, a.stop)
   if (boxes) {
     if (q == 2) ICPK_LAUNCH(2, true); else ICPK_LAUNCH(1, true);
   } else {

@@ -53,7 +53,8 @@ __global__ __launch_bounds__(64) void nn_pruned_kernel(
     const float* __restrict__ oxp, const float* __restrict__ oyp, const float* __restrict__ ozp,
     const int* __restrict__ tperm, const int* __restrict__ qperm, const float* __restrict__ tbox, int tbox_stride,
     const float* __restrict__ sbox, int sbox_stride, const nn_key_t* __restrict__ seed, int seed_scale,
-    nn_key_t* __restrict__ best) {
+    nn_key_t* __restrict__ best, const int* __restrict__ stop) {
+  if (loop_stopped(stop)) return;
   __shared__ int tile_list[64];
   __shared__ int sub_list[NP_MAX_SUBS];
   __shared__ float sub_box[6][NP_MAX_SUBS];  // boxes of the candidates, for the per-lane re-test
@@ -200,7 +201,7 @@ void launch_nn_pruned(const NnArgs& a, const nn_key_t* seed, int seed_scale, con
   const int ntiles = a.nt_pad / NN_TILE;
   hipLaunchKernelGGL(nn_pruned_kernel, dim3((a.nq + 63) / 64), dim3(64), 0, s, a.qx, a.qy, a.qz, a.nq, a.tx, a.ty, a.tz,
                      ntiles, b.ox, b.oy, b.oz, b.tperm, b.qperm, b.tbox, b.tbox_stride, b.sbox, b.sbox_stride, seed,
-                     seed_scale, a.best);
+                     seed_scale, a.best, a.stop);
 }
 
 // First-sweep seeds without a brute-force pre-pass: the target whose Morton code is

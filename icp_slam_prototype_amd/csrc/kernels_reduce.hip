@@ -19,7 +19,11 @@ __global__ __launch_bounds__(RED_THREADS) void assoc_reduce_kernel(
     const nn_key_t* __restrict__ best, const float* __restrict__ ax, const float* __restrict__ ay,
     const float* __restrict__ az, int nq, const float* __restrict__ tx, const float* __restrict__ ty,
     const float* __restrict__ tz, float max_dist, int32_t* __restrict__ idx_out, float* __restrict__ dist_out,
-    double* __restrict__ partial, int* __restrict__ pcount) {
+    double* __restrict__ partial, int* __restrict__ pcount, LoopState* __restrict__ st) {
+  if (st) {
+    if (st->done | st->stop_after_transform) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0) st->sweeps += 1;  // this sweep's associations are consumed
+  }
   const int tid = threadIdx.x;
   const int P = gridDim.x * RED_THREADS;
   double v[NSUM];
@@ -71,29 +75,6 @@ __global__ __launch_bounds__(RED_THREADS) void assoc_reduce_kernel(
   if (tid == NSUM) pcount[blockIdx.x] = wc[0] + wc[1] + wc[2] + wc[3];
 }
 
-// blocks are added in block order by one lane per quantity; the partials are
-// first staged in LDS with coalesced loads so the serial adds do not each wait
-// on a global-memory round trip
-__global__ __launch_bounds__(256) void reduce_final_kernel(const double* __restrict__ partial,
-                                                           const int* __restrict__ pcount, int nblocks, int nsum,
-                                                           double* __restrict__ out) {
-  __shared__ double sp[RED_MAX_BLOCKS * NSUM_MAX];
-  __shared__ int sc[RED_MAX_BLOCKS];
-  const int tid = threadIdx.x;
-  for (int k = tid; k < nblocks * nsum; k += 256) sp[k] = partial[k];
-  for (int k = tid; k < nblocks; k += 256) sc[k] = pcount[k];
-  __syncthreads();
-  if (tid < nsum) {
-    double t = 0.0;
-    for (int b = 0; b < nblocks; ++b) t += sp[b * nsum + tid];
-    out[tid] = t;
-  } else if (tid == nsum) {
-    long long c = 0;
-    for (int b = 0; b < nblocks; ++b) c += sc[b];
-    reinterpret_cast<long long*>(out)[nsum] = c;
-  }
-}
-
 // K5: normal equations of the linearised point-to-plane step (extension; the
 // reference only plans it, TODO:9).  Per accepted pair (dist < max_dist and a
 // non-zero target normal n): J = [p x n ; n], r = (p - q).n; 21 upper-triangle
@@ -103,7 +84,11 @@ __global__ __launch_bounds__(RED_THREADS) void p2l_reduce_kernel(
     const float* __restrict__ az, int nq, const float* __restrict__ tx, const float* __restrict__ ty,
     const float* __restrict__ tz, const float* __restrict__ nxp, const float* __restrict__ nyp,
     const float* __restrict__ nzp, float max_dist, int32_t* __restrict__ idx_out, float* __restrict__ dist_out,
-    double* __restrict__ partial, int* __restrict__ pcount) {
+    double* __restrict__ partial, int* __restrict__ pcount, LoopState* __restrict__ st) {
+  if (st) {
+    if (st->done | st->stop_after_transform) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0) st->sweeps += 1;
+  }
   const int tid = threadIdx.x;
   const int P = gridDim.x * RED_THREADS;
   double v[NP2L];
@@ -163,20 +148,20 @@ __global__ __launch_bounds__(RED_THREADS) void p2l_reduce_kernel(
 void launch_p2l_reduce(const nn_key_t* best, const float* ax, const float* ay, const float* az, int nq, const float* tx,
                        const float* ty, const float* tz, const float* nx, const float* ny, const float* nz,
                        float max_dist, int32_t* idx_out, float* dist_out, double* partial, int* pcount, double* out,
-                       hipStream_t s) {
+                       LoopState* st, hipStream_t s) {
   const int B = red_blocks(nq);
   hipLaunchKernelGGL(p2l_reduce_kernel, dim3(B), dim3(RED_THREADS), 0, s, best, ax, ay, az, nq, tx, ty, tz, nx, ny, nz,
-                     max_dist, idx_out, dist_out, partial, pcount);
-  hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(256), 0, s, partial, pcount, B, NP2L, out);
+                     max_dist, idx_out, dist_out, partial, pcount, st);
+  if (out) launch_reduce_final(partial, pcount, B, NP2L, out, s);
 }
 
 void launch_assoc_reduce(const nn_key_t* best, const float* ax, const float* ay, const float* az, int nq,
                          const float* tx, const float* ty, const float* tz, float max_dist, int32_t* idx_out,
-                         float* dist_out, double* partial, int* pcount, double* out, hipStream_t s) {
+                         float* dist_out, double* partial, int* pcount, double* out, LoopState* st, hipStream_t s) {
   const int B = red_blocks(nq);
   hipLaunchKernelGGL(assoc_reduce_kernel, dim3(B), dim3(RED_THREADS), 0, s, best, ax, ay, az, nq, tx, ty, tz,
-                     max_dist, idx_out, dist_out, partial, pcount);
-  hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(256), 0, s, partial, pcount, B, NSUM, out);
+                     max_dist, idx_out, dist_out, partial, pcount, st);
+  if (out) launch_reduce_final(partial, pcount, B, NSUM, out, s);
 }
 
 }  // namespace icpk

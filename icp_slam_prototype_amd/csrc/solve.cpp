@@ -1,287 +1,3 @@
-// solve.cpp -- host side of the ICP step: the O(1) dense algebra the reference
-// delegates to OpenCV (cv::SVD, cv::determinant, Mat::inv, 3x3 GEMM) and its
-// small pose helpers.  Plain C++, float64 internally; compiled with
-// -ffp-contract=off so results do not depend on the host compiler's fusing.
-#include "solve.h"
-
-#include <cmath>
-#include <cstring>
-#include <utility>
-
-namespace icpk {
-
-namespace {
-
-inline double col_dot(const Mat3& W, int p, int q) {
-  return W.m[0][p] * W.m[0][q] + W.m[1][p] * W.m[1][q] + W.m[2][p] * W.m[2][q];
-}
-
-inline void rotate_cols(Mat3& W, int p, int q, double c, double s) {
-  for (int r = 0; r < 3; ++r) {
-    const double wp = W.m[r][p], wq = W.m[r][q];
-    W.m[r][p] = c * wp - s * wq;
-    W.m[r][q] = s * wp + c * wq;
-  }
-}
-
-inline void cross_cols(const Mat3& U, int a, int b, double out[3]) {
-  out[0] = U.m[1][a] * U.m[2][b] - U.m[2][a] * U.m[1][b];
-  out[1] = U.m[2][a] * U.m[0][b] - U.m[0][a] * U.m[2][b];
-  out[2] = U.m[0][a] * U.m[1][b] - U.m[1][a] * U.m[0][b];
-}
-
-// R = V U^T
-inline void v_ut(const Mat3& V, const Mat3& U, double R[9]) {
-  for (int r = 0; r < 3; ++r)
-    for (int c = 0; c < 3; ++c) R[3 * r + c] = V.m[r][0] * U.m[c][0] + V.m[r][1] * U.m[c][1] + V.m[r][2] * U.m[c][2];
-}
-
-inline double det9(const double m[9]) {
-  return m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
-}
-
-}  // namespace
-
-double det3(const Mat3& A) {
-  return A.m[0][0] * (A.m[1][1] * A.m[2][2] - A.m[1][2] * A.m[2][1]) -
-         A.m[0][1] * (A.m[1][0] * A.m[2][2] - A.m[1][2] * A.m[2][0]) +
-         A.m[0][2] * (A.m[1][0] * A.m[2][1] - A.m[1][1] * A.m[2][0]);
-}
-
-// One-sided Jacobi: orthogonalise the columns of W = A V by plane rotations.
-void svd3(const Mat3& A, Mat3& U, double S[3], Mat3& V) {
-  Mat3 W = A;
-  Mat3 Q = {{{1, 0, 0}, {0, 1, 0}, {0, 0, 1}}};
-  static const int pairs[3][2] = {{0, 1}, {0, 2}, {1, 2}};
-  for (int sweep = 0; sweep < 64; ++sweep) {
-    bool any = false;
-    for (const auto& pq : pairs) {
-      const int p = pq[0], q = pq[1];
-      const double app = col_dot(W, p, p), aqq = col_dot(W, q, q), apq = col_dot(W, p, q);
-      if (apq == 0.0 || std::fabs(apq) <= 1e-17 * std::sqrt(app * aqq)) continue;
-      any = true;
-      const double zeta = (aqq - app) / (2.0 * apq);
-      const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1.0 + zeta * zeta));
-      const double c = 1.0 / std::sqrt(1.0 + t * t), s = c * t;
-      rotate_cols(W, p, q, c, s);
-      rotate_cols(Q, p, q, c, s);
-    }
-    if (!any) break;
-  }
-  double sv[3];
-  int ord[3] = {0, 1, 2};
-  for (int j = 0; j < 3; ++j) sv[j] = std::sqrt(col_dot(W, j, j));
-  for (int a = 0; a < 2; ++a)
-    for (int b = a + 1; b < 3; ++b)
-      if (sv[ord[b]] > sv[ord[a]]) std::swap(ord[a], ord[b]);
-  bool good[3];
-  for (int k = 0; k < 3; ++k) {
-    const int j = ord[k];
-    S[k] = sv[j];
-    good[k] = sv[j] > 1e-300 && sv[j] > 1e-15 * sv[ord[0]];
-    for (int r = 0; r < 3; ++r) {
-      V.m[r][k] = Q.m[r][j];
-      U.m[r][k] = good[k] ? W.m[r][j] / sv[j] : 0.0;
-    }
-  }
-  if (!good[0]) {  // zero matrix
-    U = {{{1, 0, 0}, {0, 1, 0}, {0, 0, 1}}};
-    return;
-  }
-  if (!good[1]) {  // rank 1: any unit vector orthogonal to u0
-    int mi = 0;
-    for (int r = 1; r < 3; ++r)
-      if (std::fabs(U.m[r][0]) < std::fabs(U.m[mi][0])) mi = r;
-    double v[3];
-    for (int r = 0; r < 3; ++r) v[r] = (r == mi ? 1.0 : 0.0) - U.m[mi][0] * U.m[r][0];
-    const double n = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
-    for (int r = 0; r < 3; ++r) U.m[r][1] = v[r] / n;
-  }
-  if (!good[1] || !good[2]) {
-    double c[3];
-    cross_cols(U, 0, 1, c);
-    for (int r = 0; r < 3; ++r) U.m[r][2] = c[r];
-  }
-}
-
-void solve_reference(const float M[9], float R[9]) {
-  Mat3 A, U, V;
-  double S[3], Rd[9];
-  for (int r = 0; r < 3; ++r)
-    for (int c = 0; c < 3; ++c) A.m[r][c] = M[3 * r + c];
-  svd3(A, U, S, V);
-  v_ut(V, U, Rd);  // icp.cpp:218  R = svd.vt.t() * svd.u.t()
-  double Rf[9];
-  for (int k = 0; k < 9; ++k) {
-    R[k] = (float)Rd[k];
-    Rf[k] = R[k];
-  }
-  if (det9(Rf) < 0) {  // icp.cpp:220-223: negate column 2 of R (not of V)
-    R[2] = -R[2];
-    R[5] = -R[5];
-    R[8] = -R[8];
-  }
-}
-
-bool invert3f(const float Rin[9], float out[9]) {
-  double m[9];
-  for (int k = 0; k < 9; ++k) m[k] = Rin[k];
-  double d = det9(m);
-  if (d == 0.0) {
-    std::memset(out, 0, 9 * sizeof(float));
-    return false;
-  }
-  d = 1.0 / d;
-  const double t[9] = {(m[4] * m[8] - m[5] * m[7]) * d, (m[2] * m[7] - m[1] * m[8]) * d, (m[1] * m[5] - m[2] * m[4]) * d,
-                       (m[5] * m[6] - m[3] * m[8]) * d, (m[0] * m[8] - m[2] * m[6]) * d, (m[2] * m[3] - m[0] * m[5]) * d,
-                       (m[3] * m[7] - m[4] * m[6]) * d, (m[1] * m[6] - m[0] * m[7]) * d, (m[0] * m[4] - m[1] * m[3]) * d};
-  for (int k = 0; k < 9; ++k) out[k] = (float)t[k];
-  return true;
-}
-
-void mul3f(const float A[9], const float B[9], float C[9]) {
-  float t[9];
-  for (int r = 0; r < 3; ++r)
-    for (int c = 0; c < 3; ++c) {
-      double s = 0.0;
-      for (int k = 0; k < 3; ++k) s += (double)A[3 * r + k] * (double)B[3 * k + c];
-      t[3 * r + c] = (float)s;
-    }
-  std::memcpy(C, t, sizeof(t));
-}
-
-void solve_kabsch(int64_t n, const double sa[3], const double sb[3], const double sab[9], double R[9], double t[3]) {
-  double ca[3], cb[3];
-  for (int k = 0; k < 3; ++k) {
-    ca[k] = sa[k] / (double)n;  // rigid_transform_3D.py:14-15
-    cb[k] = sb[k] / (double)n;
-  }
-  Mat3 H, U, V;
-  double S[3];
-  for (int r = 0; r < 3; ++r)
-    for (int c = 0; c < 3; ++c) H.m[r][c] = sab[3 * r + c] - (double)n * ca[r] * cb[c];  // :18-22 AA^T BB
-  svd3(H, U, S, V);
-  v_ut(V, U, R);        // :28  R = Vt.T * U.T
-  if (det9(R) < 0) {    // :31-34 negate the last row of Vt
-    for (int r = 0; r < 3; ++r) V.m[r][2] = -V.m[r][2];
-    v_ut(V, U, R);
-  }
-  for (int r = 0; r < 3; ++r) t[r] = -(R[3 * r] * ca[0] + R[3 * r + 1] * ca[1] + R[3 * r + 2] * ca[2]) + cb[r];  // :36
-}
-
-bool solve_p2l(const double sums[28], double R[9], double t[3]) {
-  double A[6][6], L[6][6] = {}, y[6], x[6];
-  for (int a = 0, k = 0; a < 6; ++a)
-    for (int b = a; b < 6; ++b, ++k) A[a][b] = A[b][a] = sums[k];
-  double dmax = 0.0;
-  for (int a = 0; a < 6; ++a) dmax = A[a][a] > dmax ? A[a][a] : dmax;
-  for (int i = 0; i < 6; ++i)
-    for (int j = 0; j <= i; ++j) {
-      double s = A[i][j];
-      for (int m = 0; m < j; ++m) s -= L[i][m] * L[j][m];
-      if (i == j) {
-        if (!(s > 1e-12 * dmax)) return false;  // not positive definite: degenerate geometry
-        L[i][i] = std::sqrt(s);
-      } else {
-        L[i][j] = s / L[j][j];
-      }
-    }
-  for (int i = 0; i < 6; ++i) {  // L y = -b
-    double s = -sums[21 + i];
-    for (int m = 0; m < i; ++m) s -= L[i][m] * y[m];
-    y[i] = s / L[i][i];
-  }
-  for (int i = 5; i >= 0; --i) {  // L^T x = y
-    double s = y[i];
-    for (int m = i + 1; m < 6; ++m) s -= L[m][i] * x[m];
-    x[i] = s / L[i][i];
-  }
-  // Rodrigues: R = I + A1 K + B1 K^2, K = [alpha]x
-  const double a0 = x[0], a1 = x[1], a2 = x[2];
-  const double th2 = (a0 * a0 + a1 * a1) + a2 * a2, th = std::sqrt(th2);
-  double A1, B1;
-  if (th < 1e-9) {
-    A1 = 1.0 - th2 / 6.0;
-    B1 = 0.5 - th2 / 24.0;
-  } else {
-    A1 = std::sin(th) / th;
-    B1 = (1.0 - std::cos(th)) / th2;
-  }
-  const double K[9] = {0, -a2, a1, a2, 0, -a0, -a1, a0, 0};
-  for (int r = 0; r < 3; ++r)
-    for (int c = 0; c < 3; ++c) {
-      const double k2 = (K[3 * r] * K[c] + K[3 * r + 1] * K[3 + c]) + K[3 * r + 2] * K[6 + c];
-      R[3 * r + c] = (r == c ? 1.0 : 0.0) + (A1 * K[3 * r + c] + B1 * k2);
-    }
-  t[0] = x[3];
-  t[1] = x[4];
-  t[2] = x[5];
-  return true;
-}
-
-void make_rotation_matrix(float x, float y, float z, float out[9]) {
-  const float PI = 3.14159265358979f;  // icp.hpp:4
-  const double rx = x * PI / 180, ry = y * PI / 180, rz = z * PI / 180;
-  const float d[9] = {1, 0, 0, 0, (float)std::cos(rx), (float)std::sin(rx), 0, (float)-std::sin(rx), (float)std::cos(rx)};
-  const float f[9] = {(float)std::cos(ry), 0, (float)-std::sin(ry), 0, 1, 0, (float)std::sin(ry), 0, (float)std::cos(ry)};
-  const float g[9] = {(float)std::cos(rz), (float)std::sin(rz), 0, (float)-std::sin(rz), (float)std::cos(rz), 0, 0, 0, 1};
-  float ab[9];
-  mul3f(d, f, ab);
-  mul3f(ab, g, out);
-}
-
-void matrix_to_quaternion(const float m[9], float q[4]) {
-  auto sgn = [](float v) { return v >= 0.0f ? 1.0f : -1.0f; };  // quaternion.hpp:22
-  const float r11 = m[0], r12 = m[1], r13 = m[2], r21 = m[3], r22 = m[4], r23 = m[5], r31 = m[6], r32 = m[7], r33 = m[8];
-  float w = (r11 + r22 + r33 + 1.0f) / 4.0f;
-  float x = (r11 - r22 - r33 + 1.0f) / 4.0f;
-  float y = (-r11 + r22 - r33 + 1.0f) / 4.0f;
-  float z = (-r11 - r22 + r33 + 1.0f) / 4.0f;
-  w = std::sqrt(w < 0.0f ? 0.0f : w);
-  x = std::sqrt(x < 0.0f ? 0.0f : x);
-  y = std::sqrt(y < 0.0f ? 0.0f : y);
-  z = std::sqrt(z < 0.0f ? 0.0f : z);
-  if (w >= x && w >= y && w >= z) {
-    x *= sgn(r32 - r23);
-    y *= sgn(r13 - r31);
-    z *= sgn(r21 - r12);
-  } else if (x >= w && x >= y && x >= z) {
-    w *= sgn(r32 - r23);
-    y *= sgn(r21 + r12);
-    z *= sgn(r13 + r31);
-  } else if (y >= w && y >= x && y >= z) {
-    w *= sgn(r13 - r31);
-    x *= sgn(r21 + r12);
-    z *= sgn(r32 + r23);
-  } else if (z >= w && z >= x && z >= y) {
-    w *= sgn(r21 - r12);
-    x *= sgn(r31 + r13);
-    y *= sgn(r32 + r23);
-  }
-  const float r = std::sqrt(w * w + x * x + y * y + z * z);  // quaternion.hpp:23
-  q[0] = w / r;
-  q[1] = x / r;
-  q[2] = y / r;
-  q[3] = z / r;
-}
-
-void quaternion_to_euler(const float q[4], float e[3]) {
-  const float PI = 3.14159265358979f;
-  const float qw = q[0], qx = q[1], qy = q[2], qz = q[3];
-  const float ysqr = qy * qy;
-  const float t0 = 2.0f * (qw * qx + qy * qz);
-  const float t1 = 1.0f - 2.0f * (qx * qx + ysqr);
-  const float ex = std::atan2(t0, t1);
-  float t2 = 2.0f * (qw * qy - qz * qx);
-  t2 = t2 > 1.0f ? 1.0f : t2;
-  t2 = t2 < -1.0f ? -1.0f : t2;
-  const float ey = std::asin(t2);
-  const float t3 = 2.0f * (qw * qz + qx * qy);
-  const float t4 = 1.0f - 2.0f * (ysqr + qz * qz);
-  const float ez = std::atan2(t3, t4);
-  e[0] = ex * 180.0f / PI;
-  e[1] = ey * 180.0f / PI;
-  e[2] = ez * 180.0f / PI;
-}
-
-}  // namespace icpk
+// solve.cpp -- the implementations live in solve_impl.h (shared host/device); this
+// translation unit only anchors them for the host side of libicpk.so.
+#include "solve_impl.h"

@@ -72,8 +72,8 @@ extern "C" {
 /* Canonical reduction geometry (part of the ABI: it fixes the summation order
  * of icpk_reduce so results are bit-reproducible and checkable): 256-thread
  * blocks, B = clamp(ceil(n/256), 1, 256) blocks, thread g sums elements
- * g, g+256B, ... in order; 64-lane xor butterfly; ((w0+w1)+w2)+w3; blocks in
- * order. */
+ * g, g+256B, ... in order; 64-lane xor butterfly; ((w0+w1)+w2)+w3; the B block
+ * sums (padded to 256 slots with +0.0) go through the same 4-wave tree again. */
 #define ICPK_RED_THREADS 256
 #define ICPK_RED_MAX_BLOCKS 256
 #define ICPK_NP2L 28 /* point-to-plane sums: [0..20] upper triangle of J J^T (row-major),  \
@@ -94,6 +94,10 @@ typedef struct icpk_params {
   int32_t profile;          /* 1: bracket every kernel with HIP events -> stats   */
   float last_rotation[9];    /* caller's previous motion, icp.cpp:23,176          */
   float last_translation[3]; /* icp.cpp:25,177                                    */
+  int32_t host_loop;        /* 0 (default): every iteration's kernels are enqueued up front
+                               and the loop test / solve run on the device (no host round
+                               trip per iteration); 1: the host drives each iteration and
+                               solves (one 160-byte read-back per iteration).  Same results. */
 } icpk_params;
 
 typedef struct icpk_stats {

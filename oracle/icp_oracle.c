@@ -187,6 +187,33 @@ ORC_API int orc_cross_moment_seq(const float *ax, const float *ay,
   return count;
 }
 
+#define ORC_NS_MAX 28
+/* Canonical tree, shared by both reductions.  acc: [B*256][ns] per-virtual-thread
+ * sums.  Stage 1 (per block of 256): 64-lane xor butterfly (32,16,...,1) in each of
+ * the 4 waves, then ((w0+w1)+w2)+w3.  Stage 2: the B block sums fill 256 slots (rest
+ * +0.0) and are combined by exactly the same 4-wave butterfly tree.                 */
+static void orc_tree256(const double *v /*[256][ns]*/, int ns, double *out) {
+  double w[4][ORC_NS_MAX];
+  double lane[64][ORC_NS_MAX], nxt[64][ORC_NS_MAX];
+  for (int wv = 0; wv < 4; wv++) {
+    for (int l = 0; l < 64; l++) memcpy(lane[l], v + (size_t)(wv * 64 + l) * ns, sizeof(double) * ns);
+    for (int m = 32; m >= 1; m >>= 1) {
+      for (int l = 0; l < 64; l++)
+        for (int s = 0; s < ns; s++) nxt[l][s] = lane[l][s] + lane[l ^ m][s];
+      memcpy(lane, nxt, sizeof(lane));
+    }
+    memcpy(w[wv], lane[0], sizeof(double) * ns);
+  }
+  for (int s = 0; s < ns; s++) out[s] = ((w[0][s] + w[1][s]) + w[2][s]) + w[3][s];
+}
+
+static void orc_tree_finish(const double *acc, int B, int ns, double *sums) {
+  double *slots = (double *)calloc((size_t)256 * ns, sizeof(double));
+  for (int b = 0; b < B; b++) orc_tree256(acc + (size_t)b * 256 * ns, ns, slots + (size_t)b * ns);
+  orc_tree256(slots, ns, sums);
+  free(slots);
+}
+
 /* ------------------------------------------------------------------------ */
 /* Canonical (order-defined) double reduction.  This is NOT in the           */
 /* reference; it defines a summation tree that a parallel machine can        */
@@ -194,7 +221,8 @@ ORC_API int orc_cross_moment_seq(const float *ax, const float *ay,
 /*   B = clamp(ceil(nq/256), 1, 256) blocks of 256 virtual threads;          */
 /*   thread g accumulates elements g, g+P, g+2P ... (P = 256 B) in order;    */
 /*   64-lane xor butterfly (32,16,8,4,2,1); the 4 wave sums of a block are   */
-/*   added ((w0+w1)+w2)+w3; blocks are added in block order.                 */
+/*   added ((w0+w1)+w2)+w3; the B block sums (padded to 256 with +0.0) go    */
+/*   through the same 4-wave butterfly tree once more.                       */
 /* sums layout: [0..8] M (row-major, M[r][c] = sum b_r a_c), [9..11] S =     */
 /* sum (float)(a-b), [12] E = sum dist, [13..15] A = sum a, [16..18] B =     */
 /* sum b.  Returns the accepted count.                                       */
@@ -226,26 +254,7 @@ ORC_API int64_t orc_sums_canonical(const float *ax, const float *ay,
       count++;
     }
   }
-  for (int s = 0; s < ORC_NSUM; s++) sums[s] = 0.0;
-  for (int b = 0; b < B; b++) {
-    double wsum[4][ORC_NSUM];
-    for (int w = 0; w < 4; w++) {
-      double lane[64][ORC_NSUM], nxt[64][ORC_NSUM];
-      for (int l = 0; l < 64; l++)
-        memcpy(lane[l], acc + ((size_t)b * ORC_RED_THREADS + w * 64 + l) * ORC_NSUM,
-               sizeof(double) * ORC_NSUM);
-      for (int m = 32; m >= 1; m >>= 1) {
-        for (int l = 0; l < 64; l++)
-          for (int s = 0; s < ORC_NSUM; s++) nxt[l][s] = lane[l][s] + lane[l ^ m][s];
-        memcpy(lane, nxt, sizeof(lane));
-      }
-      memcpy(wsum[w], lane[0], sizeof(double) * ORC_NSUM);
-    }
-    for (int s = 0; s < ORC_NSUM; s++) {
-      double t = ((wsum[0][s] + wsum[1][s]) + wsum[2][s]) + wsum[3][s];
-      sums[s] += t;
-    }
-  }
+  orc_tree_finish(acc, B, ORC_NSUM, sums);
   free(acc);
   return count;
 }
@@ -740,22 +749,7 @@ ORC_API int64_t orc_sums_p2l_canonical(const float *ax, const float *ay, const f
       count++;
     }
   }
-  for (int s = 0; s < ORC_NP2L; s++) sums[s] = 0.0;
-  for (int b = 0; b < B; b++) {
-    double wsum[4][ORC_NP2L];
-    for (int w = 0; w < 4; w++) {
-      double lane[64][ORC_NP2L], nxt[64][ORC_NP2L];
-      for (int l = 0; l < 64; l++)
-        memcpy(lane[l], acc + ((size_t)b * ORC_RED_THREADS + w * 64 + l) * ORC_NP2L, sizeof(double) * ORC_NP2L);
-      for (int m = 32; m >= 1; m >>= 1) {
-        for (int l = 0; l < 64; l++)
-          for (int s = 0; s < ORC_NP2L; s++) nxt[l][s] = lane[l][s] + lane[l ^ m][s];
-        memcpy(lane, nxt, sizeof(lane));
-      }
-      memcpy(wsum[w], lane[0], sizeof(double) * ORC_NP2L);
-    }
-    for (int s = 0; s < ORC_NP2L; s++) sums[s] += ((wsum[0][s] + wsum[1][s]) + wsum[2][s]) + wsum[3][s];
-  }
+  orc_tree_finish(acc, B, ORC_NP2L, sums);
   free(acc);
   return count;
 }

@@ -563,3 +563,65 @@ def test_config3_full_size_properties(ctx):
     assert np.array_equal(T1, T2) and st1.final_pairs == st2.final_pairs
     T3, st3, _ = ctx.align(solve=binding.SOLVE_POINT_TO_PLANE, max_iterations=15, fixed_iterations=1, max_nn_dist=0.3)
     assert np.linalg.norm(T3[:3, :3].astype(np.float64) - p["R_true"]) < 2e-3
+
+
+# ------------------------------------------------ device-side loop vs host loop --
+@pytest.mark.parametrize("solve", [binding.SOLVE_REFERENCE, binding.SOLVE_KABSCH, binding.SOLVE_POINT_TO_PLANE])
+@pytest.mark.parametrize("mode", [binding.NN_EXACT, binding.NN_FILTERED, binding.NN_PRUNED])
+def test_device_loop_equals_host_loop(ctx, oracle, solve, mode):
+    """params.host_loop = 0 (default: loop test + solve on the device, everything enqueued
+    up front) and 1 (host drives each iteration) must give the same bits."""
+    fx, cx = float(synth.K2_FX) / 4, float(synth.K2_CX) / 4
+    p = synth.kinect_pair(rows=106, cols=128, valid=1.0, seed=11, noise_sigma=0.001, fx=fx, cx=cx)
+    ctx.backproject_with_normals(p["depth_tgt"], 0, fx=fx, cx=cx, offset=[5, 5, 5])
+    ctx.set_source(p["source"])
+    out = []
+    ctx.align(solve=solve, nn_mode=mode, max_nn_dist=0.3, host_loop=1, max_iterations=7, fixed_iterations=1)
+    thr = float(ctx.get_trace()[3]["mse"])  # the loop test sees this value entering iteration 3
+    for host_loop in (1, 0):
+        for kw in (dict(max_iterations=7, fixed_iterations=1), dict(max_iterations=16, threshold=thr)):
+            T, st, rc = ctx.align(solve=solve, nn_mode=mode, max_nn_dist=0.3, host_loop=host_loop, **kw)
+            idx, dist = ctx.get_associations()
+            out.append((T.copy(), st.iterations, st.status, st.final_pairs, st.final_mse, st.nn_launches, idx, dist,
+                        ctx.get_source(), ctx.get_trace()))
+    for a, b in zip(out[:2], out[2:]):
+        assert a[1:6] == b[1:6]
+        if solve == binding.SOLVE_POINT_TO_PLANE:
+            # the Rodrigues step calls sin/cos: glibc on the host, ocml on the device
+            assert np.linalg.norm(a[0].astype(np.float64) - b[0].astype(np.float64)) < 1e-5
+            continue
+        assert np.array_equal(a[0], b[0])
+        assert np.array_equal(a[6], b[6]) and np.array_equal(a[7].view(np.uint32), b[7].view(np.uint32))
+        assert np.array_equal(a[8].view(np.uint32), b[8].view(np.uint32))
+        assert len(a[9]) == len(b[9]) == a[1]
+        for ta, tb in zip(a[9], b[9]):
+            assert np.array_equal(ta["R"], tb["R"]) and np.array_equal(ta["t"], tb["t"])
+            assert ta["n_pairs"] == tb["n_pairs"] and ta["mse"] == tb["mse"]
+    assert out[1][1] < 16  # the threshold run really exits early
+
+
+def test_device_loop_fallback_and_degenerate(ctx, oracle):
+    p = synth.frustum_pair(800, seed=5, rot_deg=(0, 0.5, 0), shift=(0.002, 0, 0))
+    far = p["source"] + np.float32(100)
+    far[:, :2] = p["target"][:, :2] + np.float32(0.05)
+    lt = np.array([1, 2, 3], np.float32)
+    ctx.set_target(p["target"])
+    ctx.set_source(far)
+    res = []
+    for host_loop in (1, 0):
+        T, st, rc = ctx.align(last_translation=lt, host_loop=host_loop)
+        res.append((T.copy(), rc, st.iterations, st.final_pairs, st.final_mse, ctx.get_source()))
+    assert res[0][1] == res[1][1] == binding.W_TOO_FEW_PAIRS and res[0][2] == res[1][2] == 0
+    assert np.array_equal(res[0][0], res[1][0]) and res[0][3:5] == res[1][3:5]
+    assert np.array_equal(res[0][5], res[1][5])
+    # point-to-plane with all normals parallel: the 6x6 system is singular -> ICPK_W_DEGENERATE
+    tgt = p["target"]
+    nrm = np.zeros_like(tgt)
+    nrm[2] = 1
+    ctx.set_target(tgt)
+    ctx.set_target_normals(nrm)
+    ctx.set_source(p["source"])
+    for host_loop in (1, 0):
+        T, st, rc = ctx.align(solve=binding.SOLVE_POINT_TO_PLANE, host_loop=host_loop, max_iterations=5,
+                              fixed_iterations=1)
+        assert rc == binding.W_DEGENERATE and st.iterations == 0 and np.array_equal(T, np.eye(4, dtype=np.float32))

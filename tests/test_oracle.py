@@ -163,15 +163,17 @@ def np_canonical(vals):
     for start in range(0, n, P):  # sequential per virtual thread
         chunk = vals[start:start + P]
         acc[: chunk.shape[0]] += chunk
-    acc = acc.reshape(B, 4, 64, k)
-    for m in (32, 16, 8, 4, 2, 1):
-        acc = acc + acc[:, :, np.arange(64) ^ m, :]
-    w = acc[:, :, 0, :]
-    blk = ((w[:, 0] + w[:, 1]) + w[:, 2]) + w[:, 3]
-    tot = np.zeros(k)
-    for b in range(B):
-        tot = tot + blk[b]
-    return tot
+    def tree256(a):  # a: (..., 256, k) -> (..., k)
+        a = a.reshape(a.shape[:-2] + (4, 64, k))
+        for m in (32, 16, 8, 4, 2, 1):
+            a = a + a[..., np.arange(64) ^ m, :]
+        w = a[..., 0, :]
+        return ((w[..., 0, :] + w[..., 1, :]) + w[..., 2, :]) + w[..., 3, :]
+
+    blk = tree256(acc.reshape(B, 256, k))
+    slots = np.zeros((256, k))
+    slots[:B] = blk
+    return tree256(slots)
 
 
 @pytest.mark.parametrize("n", [1, 63, 257, 3000, 70000])
