@@ -25,24 +25,25 @@ def _newest_src():
     return max(os.path.getmtime(p) for p in paths)
 
 
-def build(force=False, verbose=False, extra=()):
+def build(force=False, verbose=False, extra=(), out=None):
+    """out: alternative output path (diagnostic builds, e.g. tools/stamp_pruned.py)."""
     os.makedirs(LIBDIR, exist_ok=True)
-    if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= _newest_src():
+    if out is None and not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= _newest_src():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
     for s in SOURCES:
-        o = os.path.join(LIBDIR, s.rsplit(".", 1)[0] + ".o")
+        o = os.path.join(LIBDIR if out is None else os.path.dirname(out), s.rsplit(".", 1)[0] + ".o")
         cmd = [hipcc] + FLAGS + list(extra) + ["-x", "hip", "-c", os.path.join(CSRC, s), "-o", o]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)
         objs.append(o)
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out or LIB] + objs
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
-    return LIB
+    return out or LIB
 
 
 CPP_TEST = os.path.join(LIBDIR, "test_icp_align")

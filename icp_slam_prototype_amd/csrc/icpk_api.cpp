@@ -64,6 +64,9 @@ struct icpk_ctx {
   bool have_seed = false;  // `best` holds matches of a previous sweep of the same clouds
   nn_key_t* best = nullptr;
   nn_key_t* seed = nullptr;
+  nn_key_t* best_m = nullptr;  // pruned scan: results / seeds in query Morton order
+  nn_key_t* seed_m = nullptr;
+  bool have_seed_m = false;    // best_m holds the matches of the previous sweep under the current qperm
   int32_t* idx = nullptr;
   float* dist = nullptr;
   int assoc_cap = 0;
@@ -85,6 +88,7 @@ struct icpk_ctx {
   std::vector<int32_t> trace_pairs;
   int target_blocks = 16384;
   int q_per_lane = 0;  // 0 = auto
+  int slices = 4;      // pruned scan: lanes per query
   std::string err;
   icpk_log_fn log_fn = nullptr;
   void* log_user = nullptr;
@@ -126,6 +130,9 @@ int ensure_assoc(icpk_ctx* ctx, int nq) {
   if (cap > ctx->assoc_cap) {
     if (ctx->best) ICPK_HIP(ctx, hipFree(ctx->best));
     if (ctx->seed) ICPK_HIP(ctx, hipFree(ctx->seed));
+    if (ctx->best_m) ICPK_HIP(ctx, hipFree(ctx->best_m));
+    if (ctx->seed_m) ICPK_HIP(ctx, hipFree(ctx->seed_m));
+    ctx->best_m = ctx->seed_m = nullptr;
     if (ctx->idx) ICPK_HIP(ctx, hipFree(ctx->idx));
     if (ctx->dist) ICPK_HIP(ctx, hipFree(ctx->dist));
     ctx->best = ctx->seed = nullptr;
@@ -135,6 +142,8 @@ int ensure_assoc(icpk_ctx* ctx, int nq) {
     ctx->have_seed = false;
     ICPK_HIP(ctx, hipMalloc((void**)&ctx->best, (size_t)cap * sizeof(nn_key_t)));
     ICPK_HIP(ctx, hipMalloc((void**)&ctx->seed, (size_t)cap * sizeof(nn_key_t)));
+    ICPK_HIP(ctx, hipMalloc((void**)&ctx->best_m, (size_t)cap * sizeof(nn_key_t)));
+    ICPK_HIP(ctx, hipMalloc((void**)&ctx->seed_m, (size_t)cap * sizeof(nn_key_t)));
     ICPK_HIP(ctx, hipMalloc((void**)&ctx->idx, (size_t)cap * sizeof(int32_t)));
     ICPK_HIP(ctx, hipMalloc((void**)&ctx->dist, (size_t)cap * sizeof(float)));
     ctx->assoc_cap = cap;
@@ -336,26 +345,44 @@ int enqueue_nn(icpk_ctx* ctx, int nn_mode) {
     NnBoxes bx;
     rc = prepare_pruned_target(ctx, bx);
     if (rc) return rc;
+    bool new_order = false;
     if (!ctx->have_qperm || !ctx->have_seed) {
       // query order = Morton order of the source at its current pose (once per alignment);
       // the unsorted query keys stay in sort_keys[0..nq)
       rc = enqueue_morton_order(ctx, ctx->src, ctx->qperm);
       if (rc) return rc;
       ctx->have_qperm = true;
+      new_order = true;
     }
-    if (ctx->have_seed) {  // matches of the previous sweep seed this one
+    int recheck = 0;
+    if (ctx->have_seed && ctx->have_seed_m && !new_order) {
+      // matches of the previous pruned sweep, already in query Morton order
+      nn_key_t* t = ctx->seed_m;
+      ctx->seed_m = ctx->best_m;
+      ctx->best_m = t;
+      t = ctx->seed;
+      ctx->seed = ctx->best;
+      ctx->best = t;
+    } else if (ctx->have_seed) {  // matches of a sweep by another kernel: bring them into Morton order
+      launch_seed_gather(ctx->best, ctx->qperm, nq, ctx->seed_m, ctx->stream);
       nn_key_t* t = ctx->seed;
       ctx->seed = ctx->best;
       ctx->best = t;
-    } else {  // first sweep: the target with the nearest Morton code
-      launch_seed_morton(ctx->sort_keys, nq, ctx->tkeys, ctx->tperm, ctx->tgt.n, ctx->seed, ctx->stream);
+    } else {  // first sweep: the target with the nearest Morton code; loose, so re-check lazily
+      launch_seed_morton(ctx->sort_keys, ctx->qperm, nq, ctx->tkeys, ctx->tperm, ctx->tgt.n, ctx->seed_m, ctx->stream);
+      recheck = 1;
     }
     a.tx = ctx->sorted.x();
     a.ty = ctx->sorted.y();
     a.tz = ctx->sorted.z();
     a.tiles_per_chunk = ntiles;
     a.best = ctx->best;
-    launch_nn_pruned(a, ctx->seed, 1, bx, ctx->stream);
+    launch_nn_pruned(a, ctx->seed_m, ctx->best_m, bx, ctx->slices, recheck, ctx->stream);
+    ICPK_HIP(ctx, hipGetLastError());
+    ctx->have_assoc = true;
+    ctx->have_seed = true;
+    ctx->have_seed_m = true;
+    return ICPK_OK;
   } else {
     int seed_scale = 1;
     if (ctx->have_seed) {
@@ -393,6 +420,7 @@ int enqueue_nn(icpk_ctx* ctx, int nn_mode) {
   ICPK_HIP(ctx, hipGetLastError());
   ctx->have_assoc = true;
   ctx->have_seed = true;
+  ctx->have_seed_m = false;  // exact / filtered sweeps leave their matches in the caller's order only
   return ICPK_OK;
 }
 
@@ -471,6 +499,10 @@ int icpk_create(icpk_ctx** out, int device_id) {
     const int v = std::atoi(e);
     if (v > 0) ctx->target_blocks = v;
   }
+  if (const char* e = std::getenv("ICPK_NN_SLICES")) {
+    const int v = std::atoi(e);
+    if (v == 1 || v == 2 || v == 4 || v == 8) ctx->slices = v;
+  }
   if (const char* e = std::getenv("ICPK_NN_Q")) {
     const int v = std::atoi(e);
     if (v == 1 || v == 2) ctx->q_per_lane = v;
@@ -485,7 +517,7 @@ void icpk_destroy(icpk_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   for (hipEvent_t e : ctx->events) (void)hipEventDestroy(e);
-  void* dev[] = {ctx->st_dev, ctx->sorted.base, ctx->tkeys, ctx->tperm, ctx->qperm, ctx->bounds, ctx->sort_keys, ctx->sort_vals, ctx->sort_temp,
+  void* dev[] = {ctx->best_m, ctx->seed_m, ctx->st_dev, ctx->sorted.base, ctx->tkeys, ctx->tperm, ctx->qperm, ctx->bounds, ctx->sort_keys, ctx->sort_vals, ctx->sort_temp,
                  ctx->nrm.base, ctx->boxes, ctx->dec.base, ctx->tgt.base, ctx->src0.base, ctx->src.base, ctx->best,      ctx->seed,     ctx->idx,
                  ctx->dist,     ctx->partial,   ctx->pcount,   ctx->red_out,   ctx->depth_dev, ctx->bp_counts};
   for (void* p : dev)
@@ -748,6 +780,7 @@ static int align_device_loop(icpk_ctx* ctx, const icpk_params* p, float T_out[16
       ctx->best = fin;
     }
   }
+  ctx->have_seed_m = false;  // the Morton-ordered copy may belong to a skipped sweep: re-gather on demand
   const int it = h->iterations;
   if (p->solve == ICPK_SOLVE_REFERENCE) {
     for (int r = 0; r < 3; ++r) {

@@ -23,7 +23,31 @@
 
 namespace icpk {
 
-constexpr int NP_MAX_SUBS = 64 * NN_SUBS;  // passing sub-tiles of one 64-tile round
+constexpr int NP_MAX_SUBS = 16 * NN_SUBS;  // candidate sub-tiles of one chunk of 16 passing tiles
+
+// Diagnostic build only (tools/stamp_pruned.py compiles with -DICPK_NP_STAMPS): per-wave
+// s_memtime stamps of the phases, written to a buffer nothing else reads.
+#ifdef ICPK_NP_STAMPS
+__device__ unsigned long long np_dbg[8 * 4096];
+#define NP_STAMP(k)                                                                  \
+  do {                                                                               \
+    if (threadIdx.x == 0 && blockIdx.x < 4096) np_dbg[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#define NP_COUNT(k, v)                                                               \
+  do {                                                                               \
+    if (threadIdx.x == 0 && blockIdx.x < 4096) np_dbg[blockIdx.x * 8 + (k)] += (v);  \
+  } while (0)
+extern "C" int icpk_debug_read_stamps(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(np_dbg), sizeof(np_dbg));
+}
+extern "C" int icpk_debug_clear_stamps() {
+  static unsigned long long zero[8 * 4096];
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(np_dbg), zero, sizeof(zero));
+}
+#else
+#define NP_STAMP(k)
+#define NP_COUNT(k, v)
+#endif
 
 __device__ __forceinline__ float wave_min(float v) {
 #pragma unroll
@@ -47,21 +71,35 @@ __device__ __forceinline__ float box_gap2(float lox, float loy, float loz, float
   return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
 }
 
+// S = target slices per query: a wave holds 64/S queries, each replicated on S lanes that
+// scan different quarters (S = 4) of every candidate sub-tile.  More, shorter waves: with
+// ~92k queries S = 1 gives only ~1.4 waves per SIMD (issue- and latency-bound), S = 4 gives
+// ~5.6.  The S partial results of a query are merged lexicographically by xor-shuffles.
+template <int S>
 __global__ __launch_bounds__(64) void nn_pruned_kernel(
     const float* __restrict__ qxp, const float* __restrict__ qyp, const float* __restrict__ qzp, int nq,
     const float* __restrict__ txp, const float* __restrict__ typ, const float* __restrict__ tzp, int ntiles,
     const float* __restrict__ oxp, const float* __restrict__ oyp, const float* __restrict__ ozp,
     const int* __restrict__ tperm, const int* __restrict__ qperm, const float* __restrict__ tbox, int tbox_stride,
-    const float* __restrict__ sbox, int sbox_stride, const nn_key_t* __restrict__ seed, int seed_scale,
-    nn_key_t* __restrict__ best, const int* __restrict__ stop) {
+    const float* __restrict__ sbox, int sbox_stride, const nn_key_t* __restrict__ seed_m,
+    nn_key_t* __restrict__ best, nn_key_t* __restrict__ best_m, int recheck, const int* __restrict__ stop) {
+  // seed_m / best_m: seeds and results in QUERY MORTON ORDER (position ip), so the seed
+  // look-up does not wait for the qperm gather; best: results in the caller's order.
+  // recheck: re-test every candidate against the current thresholds just before it is
+  // scanned (pays off in the first sweep of an alignment, when the seeds are loose).
   if (loop_stopped(stop)) return;
+  constexpr int NQ = 64 / S;              // queries per wave
+  constexpr int SLICE = NN_SUB / S;       // targets of a sub-tile scanned by one lane
+  static_assert(SLICE % NNF_G == 0, "slice must be whole groups");
   __shared__ int tile_list[64];
   __shared__ int sub_list[NP_MAX_SUBS];
   __shared__ float sub_box[6][NP_MAX_SUBS];  // boxes of the candidates, for the per-lane re-test
   __shared__ __attribute__((aligned(16))) float stage[3][NN_SUB];
 
+  NP_STAMP(0);
   const int lane = threadIdx.x;
-  const int ip = blockIdx.x * 64 + lane;
+  const int slice = lane / NQ;
+  const int ip = blockIdx.x * NQ + (lane % NQ);
   const bool live = ip < nq;
   const int i = live ? qperm[ip] : 0;
   float qx[1], qy[1], qz[1], bd[1], T[1];
@@ -70,7 +108,7 @@ __global__ __launch_bounds__(64) void nn_pruned_kernel(
   qy[0] = live ? qyp[i] : 0.f;
   qz[0] = live ? qzp[i] : 0.f;
   {
-    int js = live ? (int)(unsigned)(seed[i] & 0xffffffffu) * seed_scale : 0;
+    int js = live ? (int)(unsigned)(seed_m[ip] & 0xffffffffu) : 0;
     float ds = pair_dist(qx[0], qy[0], qz[0], oxp[js], oyp[js], ozp[js]);
     if (!(ds <= 3.402823466e38f)) {  // inf/NaN: the reference's literal seed, element 0
       js = 0;
@@ -92,9 +130,16 @@ __global__ __launch_bounds__(64) void nn_pruned_kernel(
   // a NaN query leaves the box untouched but must see every target
   const bool weird = live && !(qx[0] - qx[0] == 0.f && qy[0] - qy[0] == 0.f && qz[0] - qz[0] == 0.f);
   const bool any_weird = __builtin_amdgcn_ballot_w64(weird) != 0;
+  NP_STAMP(1);  // init + wave box done
+
+  auto survives = [&](int s) -> bool {
+    const bool h = any_weird || box_may_hit<1>(qx, qy, qz, sub_box[0][s], sub_box[1][s], sub_box[2][s],
+                                               sub_box[3][s], sub_box[4][s], sub_box[5][s], T);
+    return __builtin_amdgcn_ballot_w64(h) != 0;
+  };
 
   for (int tb = 0; tb < ntiles; tb += 64) {
-    const float tmax = any_weird ? __builtin_inff() : wave_max(T[0]) * (1.0f + 0x1p-19f);
+    float tmax = any_weird ? __builtin_inff() : wave_max(T[0]) * (1.0f + 0x1p-19f);
     // ---- tile pass: lane <-> tile ----
     const int t = tb + lane;
     bool tp = false;
@@ -104,114 +149,171 @@ __global__ __launch_bounds__(64) void nn_pruned_kernel(
     const unsigned long long tm = __builtin_amdgcn_ballot_w64(tp);
     if (tm == 0) continue;
     const int ntl = __popcll(tm);
+    __syncthreads();  // the previous round's lists are no longer read
     if (tp) tile_list[__popcll(tm & ((1ull << lane) - 1ull))] = t;
     __syncthreads();
-    // ---- sub-tile pass: 8 tiles x 8 sub-tiles per round ----
-    int nsl = 0;
-    for (int g = 0; g < ntl; g += 8) {
-      const int ti = g + (lane >> 3);
-      bool sp = false;
-      int sb = 0;
-      if (ti < ntl) {
-        sb = tile_list[ti] * NN_SUBS + (lane & 7);
-        sp = box_gap2(sbox[sb], sbox[sbox_stride + sb], sbox[2 * sbox_stride + sb], sbox[3 * sbox_stride + sb],
-                      sbox[4 * sbox_stride + sb], sbox[5 * sbox_stride + sb], alo, ahi) <= tmax;
-      }
-      const unsigned long long sm = __builtin_amdgcn_ballot_w64(sp);
-      if (sp) {
-        const int w = nsl + __popcll(sm & ((1ull << lane) - 1ull));
-        sub_list[w] = sb;
+    // ---- passing tiles, 16 at a time (<= 128 candidate sub-tiles in LDS) ----
+    for (int g0 = 0; g0 < ntl; g0 += 16) {
+      if (g0) tmax = any_weird ? __builtin_inff() : wave_max(T[0]) * (1.0f + 0x1p-19f);
+      int nsl = 0;
+      __syncthreads();  // candidates of the previous chunk fully consumed
 #pragma unroll
-        for (int c = 0; c < 6; ++c) sub_box[c][w] = sbox[c * sbox_stride + sb];
+      for (int h = 0; h < 2; ++h) {  // sub-tile pass: lane <-> (tile, sub-tile), 8 x 8 per step
+        const int ti = g0 + 8 * h + (lane >> 3);
+        bool sp = false;
+        int sb = 0;
+        if (ti < ntl && ti < g0 + 16) {
+          sb = tile_list[ti] * NN_SUBS + (lane & 7);
+          sp = box_gap2(sbox[sb], sbox[sbox_stride + sb], sbox[2 * sbox_stride + sb], sbox[3 * sbox_stride + sb],
+                        sbox[4 * sbox_stride + sb], sbox[5 * sbox_stride + sb], alo, ahi) <= tmax;
+        }
+        const unsigned long long sm = __builtin_amdgcn_ballot_w64(sp);
+        if (sp) {
+          const int w = nsl + __popcll(sm & ((1ull << lane) - 1ull));
+          sub_list[w] = sb;
+#pragma unroll
+          for (int c = 0; c < 6; ++c) sub_box[c][w] = sbox[c * sbox_stride + sb];
+        }
+        nsl += __popcll(sm);
       }
-      nsl += __popcll(sm);
-    }
-    __syncthreads();
-    if (nsl == 0) continue;
-    // ---- scan.  Before a candidate is scanned it is re-tested per lane (lane <-> query
-    // again) against the CURRENT thresholds: the wave box can be much larger than the
-    // union of the queries' own search balls (a Morton run may straddle a jump of the
-    // curve) and the thresholds tighten as soon as the first few sub-tiles are scanned.
-    // Candidate boxes come back from LDS by broadcast.  The next surviving candidate's
-    // 128 targets are loaded into registers while the current one is scanned. ----
-    auto survives = [&](int s) -> bool {
-      const bool h = any_weird || box_may_hit<1>(qx, qy, qz, sub_box[0][s], sub_box[1][s], sub_box[2][s],
-                                                 sub_box[3][s], sub_box[4][s], sub_box[5][s], T);
-      return __builtin_amdgcn_ballot_w64(h) != 0;
-    };
-    auto next_surviving = [&](int s) -> int {
-      while (s < nsl && !survives(s)) ++s;
-      return s;
-    };
-    float px0, px1, py0, py1, pz0, pz1;
-    auto load = [&](int s) {
-      const int o = sub_list[s] * NN_SUB + lane;
-      px0 = txp[o];
-      px1 = txp[o + 64];
-      py0 = typ[o];
-      py1 = typ[o + 64];
-      pz0 = tzp[o];
-      pz1 = tzp[o + 64];
-    };
-    int cur = next_surviving(0);
-    if (cur < nsl) load(cur);
-    while (cur < nsl) {
-      __syncthreads();  // previous sub-tile fully consumed
-      stage[0][lane] = px0;
-      stage[0][64 + lane] = px1;
-      stage[1][lane] = py0;
-      stage[1][64 + lane] = py1;
-      stage[2][lane] = pz0;
-      stage[2][64 + lane] = pz1;
       __syncthreads();
-      int nxt = next_surviving(cur + 1);  // judged with the thresholds before this scan
-      if (nxt < nsl) load(nxt);           // in flight during the scan
-      const int jbase = sub_list[cur] * NN_SUB;
+      NP_COUNT(5, nsl);  // coarse candidates
+      if (nsl == 0) continue;
+      NP_STAMP(2);
+      // ---- eager per-lane re-test (lane <-> query again) with the thresholds as they are
+      // now: the wave box can be much larger than the union of the queries' own search balls
+      // (a Morton run may straddle a jump of the curve).  Candidate boxes come back from LDS
+      // by broadcast, 8 per step so the read latencies overlap; survivors compacted in place.
+      {
+        int keep = 0;
+        for (int s0 = 0; s0 < nsl; s0 += 8) {
+          unsigned hitbits = 0;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const int sc = s0 + k < nsl ? s0 + k : nsl - 1;  // clamp: duplicates are masked below
+            const bool h = any_weird || box_may_hit<1>(qx, qy, qz, sub_box[0][sc], sub_box[1][sc], sub_box[2][sc],
+                                                       sub_box[3][sc], sub_box[4][sc], sub_box[5][sc], T);
+            if (__builtin_amdgcn_ballot_w64(h) != 0 && s0 + k < nsl) hitbits |= 1u << k;
+          }
+          while (hitbits) {
+            const int k = __builtin_ctz(hitbits);
+            hitbits &= hitbits - 1;
+            const int sc = s0 + k;  // keep <= sc: in place; LDS operations of one wave execute in order
+            if (lane < 6) sub_box[lane][keep] = sub_box[lane][sc];
+            if (lane == 6) sub_list[keep] = sub_list[sc];
+            ++keep;
+          }
+        }
+        nsl = keep;
+        __syncthreads();
+        NP_COUNT(6, nsl);  // survivors
+        NP_STAMP(3);
+        if (nsl == 0) continue;
+      }
+      // ---- scan.  Each candidate is re-tested (lazily) against the CURRENT thresholds just
+      // before it is scanned; the next surviving candidate's 128 targets are loaded into
+      // registers while the current one is scanned. ----
+      auto next_surviving = [&](int s) -> int {
+        while (s < nsl && !survives(s)) ++s;
+        return s;
+      };
+      float px0, px1, py0, py1, pz0, pz1;
+      auto load = [&](int s) {
+        const int o = sub_list[s] * NN_SUB + lane;
+        px0 = txp[o];
+        px1 = txp[o + 64];
+        py0 = typ[o];
+        py1 = typ[o + 64];
+        pz0 = tzp[o];
+        pz1 = tzp[o + 64];
+      };
+      int cur = recheck ? next_surviving(0) : 0;
+      if (cur < nsl) load(cur);
+      while (cur < nsl) {
+        __syncthreads();  // previous sub-tile fully consumed
+        stage[0][lane] = px0;
+        stage[0][64 + lane] = px1;
+        stage[1][lane] = py0;
+        stage[1][64 + lane] = py1;
+        stage[2][lane] = pz0;
+        stage[2][64 + lane] = pz1;
+        __syncthreads();
+        int nxt = recheck ? next_surviving(cur + 1) : cur + 1;  // judged with the thresholds before this scan
+        if (nxt < nsl) load(nxt);                                // in flight during the scan
+        const int jbase = sub_list[cur] * NN_SUB + slice * SLICE;
+        NP_COUNT(7, 1);  // sub-tiles scanned
 #pragma unroll 2
-      for (int g = 0; g < NN_SUB; g += NNF_G) {
-        float X[NNF_G], Y[NNF_G], Z[NNF_G];
-        const float4 xa = *reinterpret_cast<const float4*>(&stage[0][g]);  // same address in every lane:
-        const float4 xb = *reinterpret_cast<const float4*>(&stage[0][g + 4]);  // LDS broadcast
-        const float4 ya = *reinterpret_cast<const float4*>(&stage[1][g]);
-        const float4 yb = *reinterpret_cast<const float4*>(&stage[1][g + 4]);
-        const float4 za = *reinterpret_cast<const float4*>(&stage[2][g]);
-        const float4 zb = *reinterpret_cast<const float4*>(&stage[2][g + 4]);
-        X[0] = xa.x; X[1] = xa.y; X[2] = xa.z; X[3] = xa.w; X[4] = xb.x; X[5] = xb.y; X[6] = xb.z; X[7] = xb.w;
-        Y[0] = ya.x; Y[1] = ya.y; Y[2] = ya.z; Y[3] = ya.w; Y[4] = yb.x; Y[5] = yb.y; Y[6] = yb.z; Y[7] = yb.w;
-        Z[0] = za.x; Z[1] = za.y; Z[2] = za.z; Z[3] = za.w; Z[4] = zb.x; Z[5] = zb.y; Z[6] = zb.z; Z[7] = zb.w;
-        float e[NNF_G][1], m[1];
-        group_estimates<1>(qx, qy, qz, X, Y, Z, e, m);
-        if (__builtin_amdgcn_ballot_w64(m[0] <= T[0]) != 0)
-          group_exact<1, true>(qx, qy, qz, X, Y, Z, e, jbase + g, tperm, bd, bj, T);
+        for (int g = 0; g < SLICE; g += NNF_G) {
+          const int o = slice * SLICE + g;
+          float X[NNF_G], Y[NNF_G], Z[NNF_G];
+          const float4 xa = *reinterpret_cast<const float4*>(&stage[0][o]);  // one address per slice:
+          const float4 xb = *reinterpret_cast<const float4*>(&stage[0][o + 4]);  // LDS broadcast
+          const float4 ya = *reinterpret_cast<const float4*>(&stage[1][o]);
+          const float4 yb = *reinterpret_cast<const float4*>(&stage[1][o + 4]);
+          const float4 za = *reinterpret_cast<const float4*>(&stage[2][o]);
+          const float4 zb = *reinterpret_cast<const float4*>(&stage[2][o + 4]);
+          X[0] = xa.x; X[1] = xa.y; X[2] = xa.z; X[3] = xa.w; X[4] = xb.x; X[5] = xb.y; X[6] = xb.z; X[7] = xb.w;
+          Y[0] = ya.x; Y[1] = ya.y; Y[2] = ya.z; Y[3] = ya.w; Y[4] = yb.x; Y[5] = yb.y; Y[6] = yb.z; Y[7] = yb.w;
+          Z[0] = za.x; Z[1] = za.y; Z[2] = za.z; Z[3] = za.w; Z[4] = zb.x; Z[5] = zb.y; Z[6] = zb.z; Z[7] = zb.w;
+          float e[NNF_G][1], m[1];
+          group_estimates<1>(qx, qy, qz, X, Y, Z, e, m);
+          if (__builtin_amdgcn_ballot_w64(m[0] <= T[0]) != 0)
+            group_exact_lanes<1>(qx, qy, qz, X, Y, Z, e, jbase + g, tperm, bd, bj, T);
+        }
+        if (S > 1) {  // the S lanes of a query share the tightest threshold
+#pragma unroll
+          for (int m = NQ; m < 64; m <<= 1) T[0] = __builtin_fminf(T[0], __shfl_xor(T[0], m, 64));
+        }
+        // the prefetched candidate was judged before this scan tightened the thresholds
+        if (recheck && nxt < nsl && !survives(nxt)) {
+          nxt = next_surviving(nxt + 1);
+          if (nxt < nsl) load(nxt);
+        }
+        cur = nxt;
       }
-      // the prefetched candidate was judged before this scan tightened the thresholds
-      if (nxt < nsl && !survives(nxt)) {
-        nxt = next_surviving(nxt + 1);
-        if (nxt < nsl) load(nxt);
-      }
-      cur = nxt;
     }
-    __syncthreads();  // lists are rebuilt by the next round
   }
 
-  if (live) best[i] = ((nn_key_t)__float_as_uint(bd[0]) << 32) | (nn_key_t)(unsigned)bj[0];
+  NP_STAMP(4);
+  nn_key_t key = ((nn_key_t)__float_as_uint(bd[0]) << 32) | (nn_key_t)(unsigned)bj[0];
+  if (S > 1) {  // lexicographic (distance, index) min over the S lanes of the query
+#pragma unroll
+    for (int m = NQ; m < 64; m <<= 1) {
+      const nn_key_t o = __shfl_xor(key, m, 64);
+      key = o < key ? o : key;
+    }
+  }
+  if (live && slice == 0) {
+    best[i] = key;
+    best_m[ip] = key;
+  }
 }
 
-void launch_nn_pruned(const NnArgs& a, const nn_key_t* seed, int seed_scale, const NnBoxes& b, hipStream_t s) {
+void launch_nn_pruned(const NnArgs& a, const nn_key_t* seed_m, nn_key_t* best_m, const NnBoxes& b, int slices,
+                      int recheck, hipStream_t s) {
   const int ntiles = a.nt_pad / NN_TILE;
-  hipLaunchKernelGGL(nn_pruned_kernel, dim3((a.nq + 63) / 64), dim3(64), 0, s, a.qx, a.qy, a.qz, a.nq, a.tx, a.ty, a.tz,
-                     ntiles, b.ox, b.oy, b.oz, b.tperm, b.qperm, b.tbox, b.tbox_stride, b.sbox, b.sbox_stride, seed,
-                     seed_scale, a.best, a.stop);
+#define ICPK_LAUNCH(SL)                                                                                            \
+  hipLaunchKernelGGL(nn_pruned_kernel<SL>, dim3((a.nq + 64 / SL - 1) / (64 / SL)), dim3(64), 0, s, a.qx, a.qy, a.qz, \
+                     a.nq, a.tx, a.ty, a.tz, ntiles, b.ox, b.oy, b.oz, b.tperm, b.qperm, b.tbox, b.tbox_stride,    \
+                     b.sbox, b.sbox_stride, seed_m, a.best, best_m, recheck, a.stop)
+  switch (slices) {
+    case 1: ICPK_LAUNCH(1); break;
+    case 2: ICPK_LAUNCH(2); break;
+    case 8: ICPK_LAUNCH(8); break;
+    default: ICPK_LAUNCH(4); break;
+  }
+#undef ICPK_LAUNCH
 }
 
 // First-sweep seeds without a brute-force pre-pass: the target whose Morton code is
 // nearest to the query's (binary search in the sorted target keys).  Any index is a
 // valid seed -- it only sets the initial search radius.
-__global__ void seed_morton_kernel(const unsigned* __restrict__ qkeys, int nq, const unsigned* __restrict__ tkeys,
-                                   const int* __restrict__ tperm, int nt, nn_key_t* __restrict__ seed) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= nq) return;
-  const unsigned k = qkeys[i];
+__global__ void seed_morton_kernel(const unsigned* __restrict__ qkeys, const int* __restrict__ qperm, int nq,
+                                   const unsigned* __restrict__ tkeys, const int* __restrict__ tperm, int nt,
+                                   nn_key_t* __restrict__ seed_m) {
+  const int ip = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ip >= nq) return;
+  const unsigned k = qkeys[qperm[ip]];
   int lo = 0, hi = nt;  // first position with tkeys[pos] >= k
   while (lo < hi) {
     const int mid = (lo + hi) >> 1;
@@ -219,13 +321,26 @@ __global__ void seed_morton_kernel(const unsigned* __restrict__ qkeys, int nq, c
   }
   int pos = lo < nt ? lo : nt - 1;
   if (pos > 0 && lo < nt && (k - tkeys[pos - 1]) < (tkeys[pos] - k)) pos = pos - 1;
-  seed[i] = (nn_key_t)(unsigned)tperm[pos];
+  seed_m[ip] = (nn_key_t)(unsigned)tperm[pos];
 }
 
-void launch_seed_morton(const unsigned* qkeys, int nq, const unsigned* tkeys, const int* tperm, int nt, nn_key_t* seed,
-                        hipStream_t s) {
+// seeds from a sweep of another kernel (caller's order) -> query Morton order
+__global__ void seed_gather_kernel(const nn_key_t* __restrict__ best, const int* __restrict__ qperm, int nq,
+                                   nn_key_t* __restrict__ seed_m) {
+  const int ip = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ip < nq) seed_m[ip] = best[qperm[ip]];
+}
+
+void launch_seed_gather(const nn_key_t* best, const int* qperm, int nq, nn_key_t* seed_m, hipStream_t s) {
   if (nq <= 0) return;
-  hipLaunchKernelGGL(seed_morton_kernel, dim3((nq + 255) / 256), dim3(256), 0, s, qkeys, nq, tkeys, tperm, nt, seed);
+  hipLaunchKernelGGL(seed_gather_kernel, dim3((nq + 255) / 256), dim3(256), 0, s, best, qperm, nq, seed_m);
+}
+
+void launch_seed_morton(const unsigned* qkeys, const int* qperm, int nq, const unsigned* tkeys, const int* tperm, int nt,
+                        nn_key_t* seed_m, hipStream_t s) {
+  if (nq <= 0) return;
+  hipLaunchKernelGGL(seed_morton_kernel, dim3((nq + 255) / 256), dim3(256), 0, s, qkeys, qperm, nq, tkeys, tperm, nt,
+                     seed_m);
 }
 
 }  // namespace icpk

@@ -78,6 +78,33 @@ __device__ __forceinline__ void group_exact(const float (&qx)[Q], const float (&
   }
 }
 
+// Same slow path when the targets differ per lane (the sliced pruned scan): X/Y/Z are
+// per-lane values, j the per-lane position of the group in the scanned planes.
+template <int Q>
+__device__ __forceinline__ void group_exact_lanes(const float (&qx)[Q], const float (&qy)[Q], const float (&qz)[Q],
+                                                  const float (&X)[NNF_G], const float (&Y)[NNF_G],
+                                                  const float (&Z)[NNF_G], const float (&e)[NNF_G][Q], int j,
+                                                  const int* __restrict__ tperm, float (&bd)[Q], int (&bj)[Q],
+                                                  float (&T)[Q]) {
+#pragma unroll
+  for (int k = 0; k < NNF_G; ++k) {
+    bool hit = false;
+#pragma unroll
+    for (int u = 0; u < Q; ++u) hit |= (e[k][u] <= T[u]);
+    if (__builtin_amdgcn_ballot_w64(hit) != 0) {
+      const int jj = tperm[j + k];  // per-lane gather (rare path)
+#pragma unroll
+      for (int u = 0; u < Q; ++u) {
+        const float d = pair_dist(qx[u], qy[u], qz[u], X[k], Y[k], Z[k]);
+        const bool up = (d < bd[u]) | ((d == bd[u]) & (jj < bj[u]));
+        bd[u] = up ? d : bd[u];
+        bj[u] = up ? jj : bj[u];
+        T[u] = up ? filt_threshold(d) : T[u];
+      }
+    }
+  }
+}
+
 // Lower bound of the squared distance from the lane's queries to an axis-aligned
 // box; true if some query of this lane may still find a passing target inside.
 // lb (fp32) <= s_j (1 + 6*2^-24) for every target j in the box, and a target passes

@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from icp_slam_prototype_amd import binding, synth
 
-def run(name, src, tgt, mode=binding.NN_PRUNED, iters=10, solve=binding.SOLVE_KABSCH):
+def run(name, src, tgt, mode=binding.NN_PRUNED, iters=60, solve=binding.SOLVE_KABSCH):
     ctx = binding.Context(0)
     ctx.set_target(tgt); ctx.set_source(src)
     p = binding.default_params(max_iterations=iters, fixed_iterations=1, profile=1, nn_mode=mode, solve=solve)
