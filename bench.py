@@ -207,7 +207,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32 coordinates, f64 pair arithmetic (reference float semantics)",
+            "dtype": "f32 filter + f64 exact pair arithmetic (reference float semantics), f64 reductions",
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: {nq} source x {nt} target points, {args.iters} fixed ICP "
                                    f"iterations per step, solve={args.solve}, nn={args.nn_mode}",
@@ -216,15 +216,35 @@ def main():
             "nn_gpairs_per_s_wall": total_pairs / elapsed / 1e9,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": {"exact": "nn_exact_kernel", "filtered": "nn_filtered_kernel<Q,false>",
-                                    "pruned": "nn_filtered_kernel<Q,true>"}[args.nn_mode],
+                         "kernel": {"exact": "nn_exact_kernel", "filtered": "nn_filtered_kernel<2>",
+                                    "pruned": "nn_pruned_kernel<4>"}[args.nn_mode],
                          "avg_launch_ms": avg_nn_s * 1e3, "algorithmic_bytes_per_launch": alg_bytes,
                          "gpairs_per_s_kernel": nq * nt / avg_nn_s / 1e9,
-                         "note": "algorithmic operand bytes (LDS tiling re-uses each target tile across 256 "
-                                 "queries, so compulsory HBM traffic is ~3 MB/launch; the kernel is VALU-bound)"},
+                         "note": "algorithmic operand bytes of the brute-force scan this kernel replaces "
+                                 "(Nq*Nt*12 + Nq*20); the pruned kernel returns the same result while skipping "
+                                 "target boxes that are out of reach, so this is not physical traffic; see "
+                                 "roofline_bruteforce for the kernel that evaluates every pair"},
             "stage_ms_per_step": {"nn": nn_ms / args.steps, "reduce": red_ms / args.steps,
                                   "transform": tr_ms / args.steps},
         }
+        if world == 1 and args.nn_mode == "pruned":
+            # the same sweep by the brute-force (un-pruned) filtered kernel, for the roofline
+            # of the kernel north_star names: every one of the Nq*Nt pairs is evaluated
+            ctx.reset_source()
+            ctx.nn(binding.NN_FILTERED, fetch=False)  # seeds
+            reps = 5
+            torch.cuda.synchronize()
+            tb = time.perf_counter()
+            for _ in range(reps):
+                ctx.nn(binding.NN_FILTERED, fetch=False)
+            t_bf = (time.perf_counter() - tb) / reps
+            out["roofline_bruteforce"] = {
+                "bound": "hbm", "kernel": "nn_filtered_kernel<2>", "achieved": alg_bytes / t_bf / 1e9,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg_bytes / t_bf / 1e9 / HBM_PEAK_GBS,
+                "avg_launch_ms": t_bf * 1e3, "gpairs_per_s_kernel": nq * nt / t_bf / 1e9,
+                "timing": "host wall clock around icpk_nn (includes one launch + sync, ~2%)",
+                "traffic": (json.load(open(tfile)).get(f"{args.workload}:filtered") if os.path.exists(tfile) else None)}
+            ctx.reset_source()
         if world == 1:
             # PCIe-inclusive rate (never `value`): the boundary handed host buffers, so
             # every step re-uploads both clouds (pageable memory) before aligning
@@ -232,7 +252,11 @@ def main():
             params.profile = 0
             t1 = time.perf_counter()
             for _ in range(reps):
-                ctx.set_target(tgt_h)
+                if args.solve == "p2l":  # the depth image crosses PCIe; cloud and normals are built on the device
+                    ctx.backproject_with_normals(w["depth_tgt"], binding.NORMALS_CROSS, offset=[5, 5, 5],
+                                                 fx=float(w["fx"]), cx=float(w["cx"]))
+                else:
+                    ctx.set_target(tgt_h)
                 ctx.set_source(src_h)
                 ctx.align(params)
             out["pcie_inclusive_iter_s"] = reps * args.iters / (time.perf_counter() - t1)

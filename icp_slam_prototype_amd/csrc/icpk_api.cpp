@@ -415,7 +415,7 @@ int enqueue_nn(icpk_ctx* ctx, int nn_mode) {
     a.tiles_per_chunk = chunking((nq + NN_THREADS * q - 1) / (NN_THREADS * q), ntiles);
     a.best = ctx->best;
     launch_fill_u64(ctx->best, nq, NN_KEY_INIT, ctx->stop, ctx->stream);
-    launch_nn_filtered(a, ctx->seed, seed_scale, q, nullptr, ctx->stream);
+    launch_nn_filtered(a, ctx->seed, seed_scale, q, ctx->stream);
   }
   ICPK_HIP(ctx, hipGetLastError());
   ctx->have_assoc = true;

@@ -83,9 +83,7 @@ int launch_sort_pairs(void* temp, size_t temp_bytes, const unsigned* keys_in, un
                       int* vals_out, int n, hipStream_t s);
 void launch_gather_planes(const float* x, const float* y, const float* z, const int* perm, int n, int n_pad, float pad,
                           float* ox, float* oy, float* oz, int* perm_pad, hipStream_t s);
-// boxes == nullptr: brute force over every target
-void launch_nn_filtered(const NnArgs& a, const nn_key_t* seed, int seed_scale, int q_per_lane, const NnBoxes* boxes,
-                        hipStream_t s);
+void launch_nn_filtered(const NnArgs& a, const nn_key_t* seed, int seed_scale, int q_per_lane, hipStream_t s);
 // kernels_nn_pruned.hip
 void launch_nn_pruned(const NnArgs& a, const nn_key_t* seed_m, nn_key_t* best_m, const NnBoxes& b, int slices,
                       int recheck, hipStream_t s);

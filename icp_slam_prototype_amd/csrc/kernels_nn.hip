@@ -181,23 +181,15 @@ __device__ __forceinline__ void scan_range(const float* __restrict__ txp, const 
   }
 }
 
-// PRUNE = false: every target of the chunk is scanned (brute force).
-// PRUNE = true : 1024-target tiles and their 128-target sub-tiles whose bounding box
-//                is farther than every lane's threshold are skipped with one test;
-//                results are identical (the test never skips a possible hit).
-template <int Q, bool PRUNE>
+// every target of the chunk is scanned (brute force over all Nq x Nt pairs); the
+// box-pruned variant lives in kernels_nn_pruned.hip
+template <int Q>
 __global__ __launch_bounds__(NN_THREADS) void nn_filtered_kernel(
     const float* __restrict__ qxp, const float* __restrict__ qyp, const float* __restrict__ qzp, int nq,
     const float* __restrict__ txp, const float* __restrict__ typ, const float* __restrict__ tzp, int nt_pad,
     int tiles_per_chunk, const nn_key_t* __restrict__ seed, int seed_scale, nn_key_t* __restrict__ best,
-    const float* __restrict__ tbox, int tbox_stride, const float* __restrict__ sbox, int sbox_stride,
-    const float* __restrict__ oxp, const float* __restrict__ oyp, const float* __restrict__ ozp,
-    const int* __restrict__ tperm, const int* __restrict__ qperm, const int* __restrict__ stop) {
+    const int* __restrict__ stop) {
   if (loop_stopped(stop)) return;
-  // PRUNE: txp/typ/tzp are the Morton-ordered target planes, oxp/oyp/ozp the caller's
-  // order (seeds index those), tperm maps scanned position -> original index and
-  // qperm lists the queries in Morton order (so a wave holds a compact cluster).
-  // !PRUNE: oxp == txp, no permutations.
   const int tid = threadIdx.x;
   const int ibase = blockIdx.x * (NN_THREADS * Q) + tid;
   float qx[Q], qy[Q], qz[Q], bd[Q], T[Q];
@@ -207,16 +199,16 @@ __global__ __launch_bounds__(NN_THREADS) void nn_filtered_kernel(
   for (int u = 0; u < Q; ++u) {
     const int ip = ibase + u * NN_THREADS;
     const bool live = ip < nq;
-    const int i = live ? (PRUNE ? qperm[ip] : ip) : 0;
+    const int i = live ? ip : 0;
     qi[u] = live ? i : -1;
     qx[u] = live ? qxp[i] : 0.f;
     qy[u] = live ? qyp[i] : 0.f;
     qz[u] = live ? qzp[i] : 0.f;
     int js = live ? (int)(unsigned)(seed[i] & 0xffffffffu) * seed_scale : 0;
-    float ds = pair_dist(qx[u], qy[u], qz[u], oxp[js], oyp[js], ozp[js]);
+    float ds = pair_dist(qx[u], qy[u], qz[u], txp[js], typ[js], tzp[js]);
     if (!(ds <= 3.402823466e38f)) {  // inf/NaN: fall back to the reference's literal seed, element 0
       js = 0;
-      ds = pair_dist(qx[u], qy[u], qz[u], oxp[0], oyp[0], ozp[0]);
+      ds = pair_dist(qx[u], qy[u], qz[u], txp[0], typ[0], tzp[0]);
     }
     bd[u] = ds;
     bj[u] = js;
@@ -229,26 +221,7 @@ __global__ __launch_bounds__(NN_THREADS) void nn_filtered_kernel(
   int tile1 = tile0 + tiles_per_chunk;
   if (tile1 > ntiles) tile1 = ntiles;
 
-  if (!PRUNE) {
-    scan_range<Q, false>(txp, typ, tzp, nullptr, tile0 * NN_TILE, tile1 * NN_TILE, qx, qy, qz, bd, bj, T);
-  } else {
-    for (int t = tile0; t < tile1; ++t) {
-      const bool th = box_may_hit<Q>(qx, qy, qz, tbox[t], tbox[tbox_stride + t], tbox[2 * tbox_stride + t],
-                                     tbox[3 * tbox_stride + t], tbox[4 * tbox_stride + t], tbox[5 * tbox_stride + t], T);
-      if (__builtin_amdgcn_ballot_w64(th) == 0) continue;
-#pragma unroll 1
-      for (int k = 0; k < NN_SUBS; ++k) {
-        const int sb = t * NN_SUBS + k;  // uniform: six scalar loads
-        const bool sh = box_may_hit<Q>(qx, qy, qz, sbox[sb], sbox[sbox_stride + sb], sbox[2 * sbox_stride + sb],
-                                       sbox[3 * sbox_stride + sb], sbox[4 * sbox_stride + sb],
-                                       sbox[5 * sbox_stride + sb], T);
-        if (__builtin_amdgcn_ballot_w64(sh) != 0) {
-          const int js = sb * NN_SUB;
-          scan_range<Q, true>(txp, typ, tzp, tperm, js, js + NN_SUB, qx, qy, qz, bd, bj, T);
-        }
-      }
-    }
-  }
+  scan_range<Q, false>(txp, typ, tzp, nullptr, tile0 * NN_TILE, tile1 * NN_TILE, qx, qy, qz, bd, bj, T);
 
 #pragma unroll
   for (int u = 0; u < Q; ++u) {
@@ -259,24 +232,17 @@ __global__ __launch_bounds__(NN_THREADS) void nn_filtered_kernel(
   }
 }
 
-void launch_nn_filtered(const NnArgs& a, const nn_key_t* seed, int seed_scale, int q_per_lane, const NnBoxes* boxes,
-                        hipStream_t s) {
+void launch_nn_filtered(const NnArgs& a, const nn_key_t* seed, int seed_scale, int q_per_lane, hipStream_t s) {
   const int ntiles = a.nt_pad / NN_TILE;
   const int nchunks = (ntiles + a.tiles_per_chunk - 1) / a.tiles_per_chunk;
   const int q = q_per_lane == 2 ? 2 : 1;
   dim3 grid((a.nq + q * NN_THREADS - 1) / (q * NN_THREADS), nchunks);
-#define ICPK_LAUNCH(Q, P)                                                                                           \
-  hipLaunchKernelGGL((nn_filtered_kernel<Q, P>), grid, dim3(NN_THREADS), 0, s, a.qx, a.qy, a.qz, a.nq, a.tx, a.ty,   \
-                     a.tz, a.nt_pad, a.tiles_per_chunk, seed, seed_scale, a.best, boxes ? boxes->tbox : nullptr,     \
-                     boxes ? boxes->tbox_stride : 0, boxes ? boxes->sbox : nullptr, boxes ? boxes->sbox_stride : 0,     \
-                     boxes ? boxes->ox : a.tx, boxes ? boxes->oy : a.ty, boxes ? boxes->oz : a.tz,                    \
-                     boxes ? boxes->tperm : nullptr, boxes ? boxes->qperm : nullptr, a.stop)
-  if (boxes) {
-    if (q == 2) ICPK_LAUNCH(2, true); else ICPK_LAUNCH(1, true);
-  } else {
-    if (q == 2) ICPK_LAUNCH(2, false); else ICPK_LAUNCH(1, false);
-  }
-#undef ICPK_LAUNCH
+  if (q == 2)
+    hipLaunchKernelGGL(nn_filtered_kernel<2>, grid, dim3(NN_THREADS), 0, s, a.qx, a.qy, a.qz, a.nq, a.tx, a.ty, a.tz,
+                       a.nt_pad, a.tiles_per_chunk, seed, seed_scale, a.best, a.stop);
+  else
+    hipLaunchKernelGGL(nn_filtered_kernel<1>, grid, dim3(NN_THREADS), 0, s, a.qx, a.qy, a.qz, a.nq, a.tx, a.ty, a.tz,
+                       a.nt_pad, a.tiles_per_chunk, seed, seed_scale, a.best, a.stop);
 }
 
 // Bounding boxes of the target cloud: one 512-lane workgroup per 1024-point tile, one

@@ -69,7 +69,7 @@ ICPK_HD void svd3(const Mat3& A, Mat3& U, double S[3], Mat3& V) {
     for (const auto& pq : pairs) {
       const int p = pq[0], q = pq[1];
       const double app = col_dot(W, p, p), aqq = col_dot(W, q, q), apq = col_dot(W, p, q);
-      if (apq == 0.0 || std::fabs(apq) <= 1e-17 * std::sqrt(app * aqq)) continue;
+      if (apq * apq <= 1e-30 * (app * aqq)) continue;  // columns orthogonal to 1e-15: R is then exact to ~1e-15
       any = true;
       const double zeta = (aqq - app) / (2.0 * apq);
       const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1.0 + zeta * zeta));

@@ -321,7 +321,7 @@ ORC_API void orc_svd3(const double A[9], double U[9], double S[3], double V[9]) 
           beta += W[3 * r + q] * W[3 * r + q];
           gamma += W[3 * r + p] * W[3 * r + q];
         }
-        if (gamma == 0.0 || fabs(gamma) <= 1e-17 * sqrt(alpha * beta)) continue;
+        if (gamma * gamma <= 1e-30 * (alpha * beta)) continue; /* orthogonal to 1e-15 */
         rotated = 1;
         double zeta = (beta - alpha) / (2.0 * gamma);
         double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
