@@ -163,6 +163,12 @@ def main():
 
     for _ in range(args.warmup):
         ctx.align(params)
+    # per-stage device times from one extra, untimed alignment (events around every stage)
+    params.profile = 2
+    _, st2, _ = ctx.align(params)
+    stage_ms = {"nn": st2.nn_ms_total, "reduce": st2.reduce_ms_total, "transform": st2.transform_ms_total,
+                "total": st2.total_ms}
+    params.profile = 1  # timed region: only the NN kernels are bracketed (2 events per sweep)
     sync_all()
     t0 = time.perf_counter()
     nn_ms = 0.0
@@ -224,8 +230,7 @@ def main():
                                  "(Nq*Nt*12 + Nq*20); the pruned kernel returns the same result while skipping "
                                  "target boxes that are out of reach, so this is not physical traffic; see "
                                  "roofline_bruteforce for the kernel that evaluates every pair"},
-            "stage_ms_per_step": {"nn": nn_ms / args.steps, "reduce": red_ms / args.steps,
-                                  "transform": tr_ms / args.steps},
+            "stage_ms_per_step": stage_ms,
         }
         if world == 1 and args.nn_mode == "pruned":
             # the same sweep by the brute-force (un-pruned) filtered kernel, for the roofline

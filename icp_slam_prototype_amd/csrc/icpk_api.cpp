@@ -704,6 +704,7 @@ int icpk_transform_source(icpk_ctx* ctx, const float R[9], const float t[3]) {
 // device (kernels_loop.hip).  Same results as the host loop below.
 static int align_device_loop(icpk_ctx* ctx, const icpk_params* p, float T_out[16], icpk_stats* stats) {
   const bool prof = p->profile != 0;
+  const bool prof_all = p->profile >= 2;  // 1: NN kernels only (2 events per sweep); 2: every stage
   const bool p2l = p->solve == ICPK_SOLVE_POINT_TO_PLANE;
   const int nsum = p2l ? NP2L : NSUM;
   const int B = red_blocks(ctx->src.n);
@@ -748,21 +749,25 @@ static int align_device_loop(icpk_ctx* ctx, const icpk_params* p, float T_out[16
     r = enqueue_nn(ctx, p->nn_mode);
     if (r) return r;
     best_of_sweep.push_back(ctx->best);
-    r = stamp(&ev_red);
+    r = stamp(prof_all ? &ev_red : nullptr);  // end of NN (= start of reduce)
     if (r) return r;
     r = p2l ? enqueue_reduce_p2l(ctx, p->max_nn_dist) : enqueue_reduce(ctx, p->max_nn_dist);
     if (r) return r;
-    return stamp(nullptr);
+    return prof_all ? stamp(nullptr) : ICPK_OK;
   };
   int rc = sweep();  // icp.cpp:98
   if (rc) return rc;
   for (int i = 0; i < p->max_iterations; ++i) {
     launch_loop_step(ctx->partial, ctx->pcount, B, nsum, ctx->st_dev, 0, ctx->stream);
-    rc = stamp(&ev_tr);
-    if (rc) return rc;
+    if (prof_all) {
+      rc = stamp(&ev_tr);
+      if (rc) return rc;
+    }
     launch_transform_state(ctx->src.x(), ctx->src.y(), ctx->src.z(), ctx->src.n, ctx->st_dev, ctx->stream);
-    rc = stamp(nullptr);
-    if (rc) return rc;
+    if (prof_all) {
+      rc = stamp(nullptr);
+      if (rc) return rc;
+    }
     rc = sweep();  // icp.cpp:255
     if (rc) return rc;
   }

@@ -91,7 +91,8 @@ typedef struct icpk_params {
   int32_t solve;            /* ICPK_SOLVE_*                                       */
   int32_t fixed_iterations; /* 1: ignore threshold, run max_iterations (bench)    */
   int32_t nn_mode;          /* ICPK_NN_*                                          */
-  int32_t profile;          /* 1: bracket every kernel with HIP events -> stats   */
+  int32_t profile;          /* 1: HIP events around the NN kernels -> stats.nn_ms_total;
+                               2: around every stage (reduce, transform) as well   */
   float last_rotation[9];    /* caller's previous motion, icp.cpp:23,176          */
   float last_translation[3]; /* icp.cpp:25,177                                    */
   int32_t host_loop;        /* 0 (default): every iteration's kernels are enqueued up front

@@ -285,9 +285,13 @@ def test_profile_stats(ctx):
     p = synth.frustum_pair(4000, seed=9)
     ctx.set_target(p["target"])
     ctx.set_source(p["source"])
+    for host_loop in (0, 1):
+        T, st, rc = ctx.align(max_iterations=3, fixed_iterations=1, profile=2, solve=binding.SOLVE_KABSCH,
+                              host_loop=host_loop)
+        assert st.nn_launches == 4 and st.nn_ms_total > 0 and st.reduce_ms_total > 0 and st.transform_ms_total > 0
+        assert st.total_ms >= st.nn_ms_total
     T, st, rc = ctx.align(max_iterations=3, fixed_iterations=1, profile=1, solve=binding.SOLVE_KABSCH)
-    assert st.nn_launches == 4 and st.nn_ms_total > 0 and st.reduce_ms_total > 0 and st.transform_ms_total > 0
-    assert st.total_ms >= st.nn_ms_total
+    assert st.nn_launches == 4 and st.nn_ms_total > 0 and st.reduce_ms_total == 0 and st.total_ms >= st.nn_ms_total
 
 
 # -------------------------------------------------------------- backproject --
