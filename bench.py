@@ -112,14 +112,23 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # Rehearsal on a 1-GPU box (never used by the driver): ICPK_BENCH_REHEARSAL=1 maps every
+    # rank to cuda:0 and runs the collectives over gloo, because RCCL refuses two ranks on
+    # one device.  The real multi-GPU run uses backend "nccl" (= RCCL over xGMI).
+    rehearsal = os.environ.get("ICPK_BENCH_REHEARSAL") == "1"
+    gpu_index = 0 if rehearsal else local_rank
+    torch.cuda.set_device(gpu_index)
+    dev = torch.device("cuda", gpu_index)
+    cdev = torch.device("cpu") if rehearsal else dev  # device of the tensors handed to collectives
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     # ---- workload: own source frame per rank; key frame (target) from rank 0 ----
     base_seed = 2
@@ -130,7 +139,7 @@ def main():
         from icp_slam_prototype_amd import batch
 
         # RCCL broadcast of the key frame's xyz-SoA over xGMI (one 3*Nt*4-byte message)
-        tgt_d = batch.broadcast_cloud(w["target"] if rank == 0 else None, 0, dev, dist)
+        tgt_d = batch.broadcast_cloud(w["target"] if rank == 0 else None, 0, cdev, dist).to(dev)
         tgt_h = tgt_d.cpu().numpy()
     else:
         tgt_h = np.ascontiguousarray(w["target"])
@@ -138,7 +147,7 @@ def main():
     torch.cuda.synchronize()
     nq, nt = src_d.shape[1], tgt_d.shape[1]
 
-    ctx = binding.Context(local_rank)
+    ctx = binding.Context(gpu_index)
     es = src_d.element_size()
     ctx.set_target_device(tgt_d.data_ptr(), tgt_d.data_ptr() + nt * es, tgt_d.data_ptr() + 2 * nt * es, nt)
     ctx.set_source_device(src_d.data_ptr(), src_d.data_ptr() + nq * es, src_d.data_ptr() + 2 * nq * es, nq)
@@ -185,10 +194,10 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-        agg = torch.tensor([iters_done, nn_launches * nq, nn_launches * nq * nt], dtype=torch.float64, device=dev)
+        agg = torch.tensor([iters_done, nn_launches * nq, nn_launches * nq * nt], dtype=torch.float64, device=cdev)
         dist.all_reduce(agg, op=dist.ReduceOp.SUM)
         total_iters, total_queries, total_pairs = (float(v) for v in agg.tolist())
     else:
