@@ -629,3 +629,31 @@ def test_device_loop_fallback_and_degenerate(ctx, oracle):
         T, st, rc = ctx.align(solve=binding.SOLVE_POINT_TO_PLANE, host_loop=host_loop, max_iterations=5,
                               fixed_iterations=1)
         assert rc == binding.W_DEGENERATE and st.iterations == 0 and np.array_equal(T, np.eye(4, dtype=np.float32))
+
+
+def test_config5_unordered_clouds_exact_vs_pruned(ctx):
+    """BASELINE config 5 shape (unordered dense cloud, source permuted) at 300k x 300k:
+    the oracle would need minutes, so check the pruned kernel (which relies on its own
+    Morton sort here -- the input has no spatial order) against the exact kernel."""
+    p = synth.dense_pair(300_000, seed=5)
+    ctx.set_target(p["target"])
+    ctx.set_source(p["source"])
+    ie, de = ctx.nn(binding.NN_EXACT)
+    ctx.reset_source()
+    ip, dp = ctx.nn(binding.NN_PRUNED)
+    assert np.array_equal(ie, ip) and np.array_equal(de.view(np.uint32), dp.view(np.uint32))
+    T1, st1, _ = ctx.align(max_iterations=3, fixed_iterations=1, solve=binding.SOLVE_KABSCH, nn_mode=binding.NN_PRUNED)
+    T2, st2, _ = ctx.align(max_iterations=3, fixed_iterations=1, solve=binding.SOLVE_KABSCH, nn_mode=binding.NN_FILTERED)
+    assert np.array_equal(T1, T2) and st1.final_pairs == st2.final_pairs
+    i1, _ = ctx.get_associations()
+    assert len(np.unique(i1)) > 0.5 * i1.size
+
+
+def test_many_iterations_uses_host_loop_and_matches(ctx, oracle):
+    """max_iterations above the device loop's trace capacity (256) falls back to the host loop."""
+    p = synth.frustum_pair(600, seed=8, rot_deg=(0, 1, 0), shift=(0.01, 0, 0))
+    ctx.set_target(p["target"])
+    ctx.set_source(p["source"])
+    T, st, rc = ctx.align(max_iterations=300, threshold=0.0, solve=binding.SOLVE_KABSCH)
+    o = oracle.align(p["source"], p["target"], max_iterations=300, threshold=0.0, solve=1, sum_order=1)
+    assert st.iterations == o["iterations"] and np.array_equal(T, o["T"])
