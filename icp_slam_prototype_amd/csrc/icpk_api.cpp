@@ -369,7 +369,9 @@ int enqueue_nn(icpk_ctx* ctx, int nn_mode) {
       ctx->seed = ctx->best;
       ctx->best = t;
     } else {  // first sweep: the target with the nearest Morton code; loose, so re-check lazily
-      launch_seed_morton(ctx->sort_keys, ctx->qperm, nq, ctx->tkeys, ctx->tperm, ctx->tgt.n, ctx->seed_m, ctx->stream);
+      launch_seed_morton(ctx->sort_keys, ctx->qperm, nq, ctx->src.x(), ctx->src.y(), ctx->src.z(), ctx->tkeys,
+                         ctx->sorted.x(), ctx->sorted.y(), ctx->sorted.z(), ctx->tperm, ctx->tgt.n, ctx->seed_m,
+                         ctx->stream);
       recheck = 1;
     }
     a.tx = ctx->sorted.x();

@@ -87,8 +87,9 @@ void launch_nn_filtered(const NnArgs& a, const nn_key_t* seed, int seed_scale, i
 // kernels_nn_pruned.hip
 void launch_nn_pruned(const NnArgs& a, const nn_key_t* seed_m, nn_key_t* best_m, const NnBoxes& b, int slices,
                       int recheck, hipStream_t s);
-void launch_seed_morton(const unsigned* qkeys, const int* qperm, int nq, const unsigned* tkeys, const int* tperm, int nt,
-                        nn_key_t* seed_m, hipStream_t s);
+void launch_seed_morton(const unsigned* qkeys, const int* qperm, int nq, const float* qx, const float* qy,
+                        const float* qz, const unsigned* tkeys, const float* sx, const float* sy, const float* sz,
+                        const int* tperm, int nt, nn_key_t* seed_m, hipStream_t s);
 void launch_seed_gather(const nn_key_t* best, const int* qperm, int nq, nn_key_t* seed_m, hipStream_t s);
 void launch_tile_boxes(const float* x, const float* y, const float* z, int n, int ntiles, const NnBoxes& b,
                        hipStream_t s);

@@ -305,23 +305,41 @@ void launch_nn_pruned(const NnArgs& a, const nn_key_t* seed_m, nn_key_t* best_m,
 #undef ICPK_LAUNCH
 }
 
-// First-sweep seeds without a brute-force pre-pass: the target whose Morton code is
-// nearest to the query's (binary search in the sorted target keys).  Any index is a
-// valid seed -- it only sets the initial search radius.
+// First-sweep seeds without a brute-force pre-pass: binary search of the query's Morton
+// code in the sorted target keys, then the nearest (fp32 distance) of the 2W+1 targets
+// around that position in the Morton-ordered planes.  Any index is a valid seed -- it
+// only sets the initial search radius -- so nothing here needs to be exact.
+constexpr int SEED_W = 8;
 __global__ void seed_morton_kernel(const unsigned* __restrict__ qkeys, const int* __restrict__ qperm, int nq,
-                                   const unsigned* __restrict__ tkeys, const int* __restrict__ tperm, int nt,
+                                   const float* __restrict__ qxp, const float* __restrict__ qyp,
+                                   const float* __restrict__ qzp, const unsigned* __restrict__ tkeys,
+                                   const float* __restrict__ sx, const float* __restrict__ sy,
+                                   const float* __restrict__ sz, const int* __restrict__ tperm, int nt,
                                    nn_key_t* __restrict__ seed_m) {
   const int ip = blockIdx.x * blockDim.x + threadIdx.x;
   if (ip >= nq) return;
-  const unsigned k = qkeys[qperm[ip]];
+  const int i = qperm[ip];
+  const unsigned k = qkeys[i];
   int lo = 0, hi = nt;  // first position with tkeys[pos] >= k
   while (lo < hi) {
     const int mid = (lo + hi) >> 1;
     if (tkeys[mid] < k) lo = mid + 1; else hi = mid;
   }
-  int pos = lo < nt ? lo : nt - 1;
-  if (pos > 0 && lo < nt && (k - tkeys[pos - 1]) < (tkeys[pos] - k)) pos = pos - 1;
-  seed_m[ip] = (nn_key_t)(unsigned)tperm[pos];
+  const float qx = qxp[i], qy = qyp[i], qz = qzp[i];
+  int a = lo - SEED_W, b = lo + SEED_W;
+  if (a < 0) a = 0;
+  if (b > nt - 1) b = nt - 1;
+  float bestv = __builtin_inff();
+  int bestp = a;
+  for (int p = a; p <= b; ++p) {
+    const float dx = qx - sx[p], dy = qy - sy[p], dz = qz - sz[p];
+    const float e = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+    if (e < bestv) {
+      bestv = e;
+      bestp = p;
+    }
+  }
+  seed_m[ip] = (nn_key_t)(unsigned)tperm[bestp];
 }
 
 // seeds from a sweep of another kernel (caller's order) -> query Morton order
@@ -336,11 +354,12 @@ void launch_seed_gather(const nn_key_t* best, const int* qperm, int nq, nn_key_t
   hipLaunchKernelGGL(seed_gather_kernel, dim3((nq + 255) / 256), dim3(256), 0, s, best, qperm, nq, seed_m);
 }
 
-void launch_seed_morton(const unsigned* qkeys, const int* qperm, int nq, const unsigned* tkeys, const int* tperm, int nt,
-                        nn_key_t* seed_m, hipStream_t s) {
+void launch_seed_morton(const unsigned* qkeys, const int* qperm, int nq, const float* qx, const float* qy,
+                        const float* qz, const unsigned* tkeys, const float* sx, const float* sy, const float* sz,
+                        const int* tperm, int nt, nn_key_t* seed_m, hipStream_t s) {
   if (nq <= 0) return;
-  hipLaunchKernelGGL(seed_morton_kernel, dim3((nq + 255) / 256), dim3(256), 0, s, qkeys, qperm, nq, tkeys, tperm, nt,
-                     seed_m);
+  hipLaunchKernelGGL(seed_morton_kernel, dim3((nq + 255) / 256), dim3(256), 0, s, qkeys, qperm, nq, qx, qy, qz, tkeys,
+                     sx, sy, sz, tperm, nt, seed_m);
 }
 
 }  // namespace icpk
