@@ -379,7 +379,7 @@ int enqueue_nn(icpk_ctx* ctx, int nn_mode) {
     a.tz = ctx->sorted.z();
     a.tiles_per_chunk = ntiles;
     a.best = ctx->best;
-    launch_nn_pruned(a, ctx->seed_m, ctx->best_m, bx, ctx->slices, recheck, ctx->stream);
+    launch_nn_pruned(a, ctx->seed_m, ctx->best_m, bx, ctx->slices, recheck, ctx->st_active, ctx->stream);
     ICPK_HIP(ctx, hipGetLastError());
     ctx->have_assoc = true;
     ctx->have_seed = true;
@@ -708,6 +708,7 @@ static int align_device_loop(icpk_ctx* ctx, const icpk_params* p, float T_out[16
   const bool prof = p->profile != 0;
   const bool prof_all = p->profile >= 2;  // 1: NN kernels only (2 events per sweep); 2: every stage
   const bool p2l = p->solve == ICPK_SOLVE_POINT_TO_PLANE;
+  const bool fused = p->nn_mode == ICPK_NN_PRUNED;  // K3 runs inside the pruned sweep
   const int nsum = p2l ? NP2L : NSUM;
   const int B = red_blocks(ctx->src.n);
   size_t nev = 0;
@@ -761,14 +762,16 @@ static int align_device_loop(icpk_ctx* ctx, const icpk_params* p, float T_out[16
   if (rc) return rc;
   for (int i = 0; i < p->max_iterations; ++i) {
     launch_loop_step(ctx->partial, ctx->pcount, B, nsum, ctx->st_dev, 0, ctx->stream);
-    if (prof_all) {
-      rc = stamp(&ev_tr);
-      if (rc) return rc;
-    }
-    launch_transform_state(ctx->src.x(), ctx->src.y(), ctx->src.z(), ctx->src.n, ctx->st_dev, ctx->stream);
-    if (prof_all) {
-      rc = stamp(nullptr);
-      if (rc) return rc;
+    if (!fused) {  // the pruned sweep applies the transform itself (K3 fused into K1c)
+      if (prof_all) {
+        rc = stamp(&ev_tr);
+        if (rc) return rc;
+      }
+      launch_transform_state(ctx->src.x(), ctx->src.y(), ctx->src.z(), ctx->src.n, ctx->st_dev, ctx->stream);
+      if (prof_all) {
+        rc = stamp(nullptr);
+        if (rc) return rc;
+      }
     }
     rc = sweep();  // icp.cpp:255
     if (rc) return rc;

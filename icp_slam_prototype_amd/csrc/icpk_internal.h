@@ -38,6 +38,7 @@ struct Rt {
   float R[9];
   float t[3];
 };
+struct LoopState;  // device-side loop state, defined below
 
 constexpr int NSUM = 19;
 constexpr int NP2L = 28;      // point-to-plane: 21 + 6 + 1
@@ -85,8 +86,9 @@ void launch_gather_planes(const float* x, const float* y, const float* z, const 
                           float* ox, float* oy, float* oz, int* perm_pad, hipStream_t s);
 void launch_nn_filtered(const NnArgs& a, const nn_key_t* seed, int seed_scale, int q_per_lane, hipStream_t s);
 // kernels_nn_pruned.hip
+// st != nullptr (device-side loop): K3 is fused into the sweep (see the kernel)
 void launch_nn_pruned(const NnArgs& a, const nn_key_t* seed_m, nn_key_t* best_m, const NnBoxes& b, int slices,
-                      int recheck, hipStream_t s);
+                      int recheck, const LoopState* st, hipStream_t s);
 void launch_seed_morton(const unsigned* qkeys, const int* qperm, int nq, const float* qx, const float* qy,
                         const float* qz, const unsigned* tkeys, const float* sx, const float* sy, const float* sz,
                         const int* tperm, int nt, nn_key_t* seed_m, hipStream_t s);

@@ -77,17 +77,26 @@ __device__ __forceinline__ float box_gap2(float lox, float loy, float loz, float
 // ~5.6.  The S partial results of a query are merged lexicographically by xor-shuffles.
 template <int S>
 __global__ __launch_bounds__(64) void nn_pruned_kernel(
-    const float* __restrict__ qxp, const float* __restrict__ qyp, const float* __restrict__ qzp, int nq,
+    float* __restrict__ qxp, float* __restrict__ qyp, float* __restrict__ qzp, int nq,
     const float* __restrict__ txp, const float* __restrict__ typ, const float* __restrict__ tzp, int ntiles,
     const float* __restrict__ oxp, const float* __restrict__ oyp, const float* __restrict__ ozp,
     const int* __restrict__ tperm, const int* __restrict__ qperm, const float* __restrict__ tbox, int tbox_stride,
     const float* __restrict__ sbox, int sbox_stride, const nn_key_t* __restrict__ seed_m,
-    nn_key_t* __restrict__ best, nn_key_t* __restrict__ best_m, int recheck, const int* __restrict__ stop) {
+    nn_key_t* __restrict__ best, nn_key_t* __restrict__ best_m, int recheck, const LoopState* __restrict__ st) {
   // seed_m / best_m: seeds and results in QUERY MORTON ORDER (position ip), so the seed
   // look-up does not wait for the qperm gather; best: results in the caller's order.
   // recheck: re-test every candidate against the current thresholds just before it is
   // scanned (pays off in the first sweep of an alignment, when the seeds are loose).
-  if (loop_stopped(stop)) return;
+  // st (device-side loop only): besides the stop flags it carries the rigid transform of
+  // the iteration that just ended; K3 is fused here -- every query belongs to exactly one
+  // wave, which moves it (same arithmetic as transform_kernel), writes it back for K2 and
+  // searches from the new position.
+  bool apply_rt = false, stop_after = false;
+  if (st) {
+    if (st->done) return;
+    stop_after = st->stop_after_transform != 0;
+    apply_rt = st->iterations > 0 || stop_after;
+  }
   constexpr int NQ = 64 / S;              // queries per wave
   constexpr int SLICE = NN_SUB / S;       // targets of a sub-tile scanned by one lane
   static_assert(SLICE % NNF_G == 0, "slice must be whole groups");
@@ -107,6 +116,19 @@ __global__ __launch_bounds__(64) void nn_pruned_kernel(
   qx[0] = live ? qxp[i] : 0.f;
   qy[0] = live ? qyp[i] : 0.f;
   qz[0] = live ? qzp[i] : 0.f;
+  if (apply_rt) {  // pointcloud.cpp:321-359: p <- fl32(fl32(R p) + t)
+    const Rt rt = st->rt;
+    const double px = qx[0], py = qy[0], pz = qz[0];
+    qx[0] = (float)__builtin_fma((double)rt.R[2], pz, __builtin_fma((double)rt.R[1], py, (double)rt.R[0] * px)) + rt.t[0];
+    qy[0] = (float)__builtin_fma((double)rt.R[5], pz, __builtin_fma((double)rt.R[4], py, (double)rt.R[3] * px)) + rt.t[1];
+    qz[0] = (float)__builtin_fma((double)rt.R[8], pz, __builtin_fma((double)rt.R[7], py, (double)rt.R[6] * px)) + rt.t[2];
+    if (live && slice == 0) {
+      qxp[i] = qx[0];
+      qyp[i] = qy[0];
+      qzp[i] = qz[0];
+    }
+    if (stop_after) return;  // < min_pairs fallback: the motion is applied, no further search
+  }
   {
     int js = live ? (int)(unsigned)(seed_m[ip] & 0xffffffffu) : 0;
     float ds = pair_dist(qx[0], qy[0], qz[0], oxp[js], oyp[js], ozp[js]);
@@ -290,12 +312,13 @@ __global__ __launch_bounds__(64) void nn_pruned_kernel(
 }
 
 void launch_nn_pruned(const NnArgs& a, const nn_key_t* seed_m, nn_key_t* best_m, const NnBoxes& b, int slices,
-                      int recheck, hipStream_t s) {
+                      int recheck, const LoopState* st, hipStream_t s) {
   const int ntiles = a.nt_pad / NN_TILE;
 #define ICPK_LAUNCH(SL)                                                                                            \
-  hipLaunchKernelGGL(nn_pruned_kernel<SL>, dim3((a.nq + 64 / SL - 1) / (64 / SL)), dim3(64), 0, s, a.qx, a.qy, a.qz, \
+  hipLaunchKernelGGL(nn_pruned_kernel<SL>, dim3((a.nq + 64 / SL - 1) / (64 / SL)), dim3(64), 0, s,               \
+                     const_cast<float*>(a.qx), const_cast<float*>(a.qy), const_cast<float*>(a.qz),                \
                      a.nq, a.tx, a.ty, a.tz, ntiles, b.ox, b.oy, b.oz, b.tperm, b.qperm, b.tbox, b.tbox_stride,    \
-                     b.sbox, b.sbox_stride, seed_m, a.best, best_m, recheck, a.stop)
+                     b.sbox, b.sbox_stride, seed_m, a.best, best_m, recheck, st)
   switch (slices) {
     case 1: ICPK_LAUNCH(1); break;
     case 2: ICPK_LAUNCH(2); break;

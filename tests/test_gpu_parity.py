@@ -288,7 +288,9 @@ def test_profile_stats(ctx):
     for host_loop in (0, 1):
         T, st, rc = ctx.align(max_iterations=3, fixed_iterations=1, profile=2, solve=binding.SOLVE_KABSCH,
                               host_loop=host_loop)
-        assert st.nn_launches == 4 and st.nn_ms_total > 0 and st.reduce_ms_total > 0 and st.transform_ms_total > 0
+        assert st.nn_launches == 4 and st.nn_ms_total > 0 and st.reduce_ms_total > 0
+        # in the device loop the pruned sweep applies the transform itself (K3 fused into K1c)
+        assert (st.transform_ms_total > 0) == (host_loop == 1)
         assert st.total_ms >= st.nn_ms_total
     T, st, rc = ctx.align(max_iterations=3, fixed_iterations=1, profile=1, solve=binding.SOLVE_KABSCH)
     assert st.nn_launches == 4 and st.nn_ms_total > 0 and st.reduce_ms_total == 0 and st.total_ms >= st.nn_ms_total
