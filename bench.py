@@ -234,6 +234,9 @@ def main():
                          "kernel": {"exact": "nn_exact_kernel", "filtered": "nn_filtered_kernel<2>",
                                     "pruned": "nn_pruned_kernel<4>"}[args.nn_mode],
                          "avg_launch_ms": avg_nn_s * 1e3, "algorithmic_bytes_per_launch": alg_bytes,
+                         "timing": "two HIP events recorded on the kernel's own stream immediately around each "
+                                   "K1 launch of the timed region (includes ~5 us of dispatch latency per launch; "
+                                   "the rocprofv3 --kernel-trace average of the same command is in profiles/)",
                          "gpairs_per_s_kernel": nq * nt / avg_nn_s / 1e9,
                          "note": "algorithmic operand bytes of the brute-force scan this kernel replaces "
                                  "(Nq*Nt*12 + Nq*20); the pruned kernel returns the same result while skipping "

@@ -300,8 +300,14 @@ int prepare_pruned_target(icpk_ctx* ctx, NnBoxes& bx) {
   return ICPK_OK;
 }
 
-// enqueue one NN sweep (K1) over the working source
-int enqueue_nn(icpk_ctx* ctx, int nn_mode) {
+// enqueue one NN sweep (K1) over the working source; ev0/ev1 (optional) are recorded
+// immediately before/after the K1 launch itself, so that set-up kernels of a first sweep
+// (sort, seeding, fills) do not count as kernel time
+int enqueue_nn(icpk_ctx* ctx, int nn_mode, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr) {
+  auto mark = [&](hipEvent_t e) -> int {
+    if (e) ICPK_HIP(ctx, hipEventRecord(e, ctx->stream));
+    return ICPK_OK;
+  };
   if (nn_mode != ICPK_NN_EXACT && nn_mode != ICPK_NN_FILTERED && nn_mode != ICPK_NN_PRUNED)
     return fail(ctx, ICPK_E_ARG, "unknown nn_mode");
   const int nq = ctx->src.n;
@@ -332,7 +338,9 @@ int enqueue_nn(icpk_ctx* ctx, int nn_mode) {
     a.tiles_per_chunk = chunking((nq + NN_THREADS - 1) / NN_THREADS, ntiles);
     a.best = ctx->best;
     launch_fill_u64(ctx->best, nq, NN_KEY_INIT, ctx->stop, ctx->stream);
+    if ((rc = mark(ev0))) return rc;
     launch_nn_exact(a, ctx->stream);
+    if ((rc = mark(ev1))) return rc;
   } else if (nn_mode == ICPK_NN_PRUNED) {
     if (round_up(nq, NN_TILE) > ctx->qperm_cap) {
       if (ctx->qperm) ICPK_HIP(ctx, hipFree(ctx->qperm));
@@ -379,7 +387,9 @@ int enqueue_nn(icpk_ctx* ctx, int nn_mode) {
     a.tz = ctx->sorted.z();
     a.tiles_per_chunk = ntiles;
     a.best = ctx->best;
+    if ((rc = mark(ev0))) return rc;
     launch_nn_pruned(a, ctx->seed_m, ctx->best_m, bx, ctx->slices, recheck, ctx->st_active, ctx->stream);
+    if ((rc = mark(ev1))) return rc;
     ICPK_HIP(ctx, hipGetLastError());
     ctx->have_assoc = true;
     ctx->have_seed = true;
@@ -417,7 +427,9 @@ int enqueue_nn(icpk_ctx* ctx, int nn_mode) {
     a.tiles_per_chunk = chunking((nq + NN_THREADS * q - 1) / (NN_THREADS * q), ntiles);
     a.best = ctx->best;
     launch_fill_u64(ctx->best, nq, NN_KEY_INIT, ctx->stop, ctx->stream);
+    if ((rc = mark(ev0))) return rc;
     launch_nn_filtered(a, ctx->seed, seed_scale, q, ctx->stream);
+    if ((rc = mark(ev1))) return rc;
   }
   ICPK_HIP(ctx, hipGetLastError());
   ctx->have_assoc = true;
@@ -747,13 +759,21 @@ static int align_device_loop(icpk_ctx* ctx, const icpk_params* p, float T_out[16
 
   std::vector<nn_key_t*> best_of_sweep;
   auto sweep = [&]() -> int {
-    int r = stamp(&ev_nn);
-    if (r) return r;
-    r = enqueue_nn(ctx, p->nn_mode);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (prof) {  // two events tightly around the K1 launch
+      e0 = get_event(ctx, nev);
+      e1 = get_event(ctx, nev + 1);
+      if (!e0 || !e1) return fail(ctx, ICPK_E_HIP, "hipEventCreate failed");
+      ev_nn.push_back(nev);
+      nev += 2;
+    }
+    int r = enqueue_nn(ctx, p->nn_mode, e0, e1);
     if (r) return r;
     best_of_sweep.push_back(ctx->best);
-    r = stamp(prof_all ? &ev_red : nullptr);  // end of NN (= start of reduce)
-    if (r) return r;
+    if (prof_all) {
+      r = stamp(&ev_red);
+      if (r) return r;
+    }
     r = p2l ? enqueue_reduce_p2l(ctx, p->max_nn_dist) : enqueue_reduce(ctx, p->max_nn_dist);
     if (r) return r;
     return prof_all ? stamp(nullptr) : ICPK_OK;
@@ -911,11 +931,17 @@ int icpk_align(icpk_ctx* ctx, const icpk_params* p, float T_out[16], icpk_stats*
   float mse = 0.f;
   int sweeps = 0;
   auto sweep = [&]() -> int {
-    int r = stamp(&ev_nn);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (prof) {  // two events tightly around the K1 launch
+      e0 = get_event(ctx, nev);
+      e1 = get_event(ctx, nev + 1);
+      if (!e0 || !e1) return fail(ctx, ICPK_E_HIP, "hipEventCreate failed");
+      ev_nn.push_back(nev);
+      nev += 2;
+    }
+    int r = enqueue_nn(ctx, p->nn_mode, e0, e1);
     if (r) return r;
-    r = enqueue_nn(ctx, p->nn_mode);
-    if (r) return r;
-    r = stamp(&ev_red);  // end of NN == start of reduce
+    r = stamp(&ev_red);  // start of reduce
     if (r) return r;
     if (ctx->src.n > 0) {
       r = p2l ? enqueue_reduce_p2l(ctx, p->max_nn_dist) : enqueue_reduce(ctx, p->max_nn_dist);
