@@ -15,6 +15,9 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(scope="module")
 def ctx():
+    from icp_slam_prototype_amd import build
+
+    build.build()  # no-op when lib/libicpk.so is up to date (hipcc is present on the GPU box too)
     c = binding.Context(0)
     yield c
     c.close()
