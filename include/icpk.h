@@ -14,7 +14,10 @@
  *
  * Data layout: point clouds are xyz structure-of-arrays (three float planes),
  * replacing the reference's 16-byte AoS color_point_t (pointcloud.hpp:13-19);
- * colour is dropped because COLOR_WEIGHT is 0.0f (icp.hpp:6).
+ * colour is dropped because COLOR_WEIGHT is 0.0f (icp.hpp:6).  Coordinates are
+ * expected to be finite (the reference produces them from uint16 depth): a NaN/inf
+ * point never faults or hangs a kernel and never pairs, but which index it reports
+ * is unspecified.
  */
 #ifndef ICPK_H
 #define ICPK_H

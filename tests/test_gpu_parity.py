@@ -662,3 +662,75 @@ def test_many_iterations_uses_host_loop_and_matches(ctx, oracle):
     T, st, rc = ctx.align(max_iterations=300, threshold=0.0, solve=binding.SOLVE_KABSCH)
     o = oracle.align(p["source"], p["target"], max_iterations=300, threshold=0.0, solve=1, sum_order=1)
     assert st.iterations == o["iterations"] and np.array_equal(T, o["T"])
+
+
+# ------------------------------------------------------------------- fuzzing --
+def _fuzz_cloud(rng, n, kind):
+    if kind == "uniform":
+        return rng.uniform(-3, 3, (3, n))
+    if kind == "clusters":
+        c = rng.uniform(-3, 3, (3, 12))
+        return c[:, rng.integers(0, 12, n)] + rng.normal(0, 0.02, (3, n))
+    if kind == "line":
+        t = rng.uniform(0, 1, n)
+        return np.stack([t * 4 - 2, 0.5 * t, np.full(n, 1.0)]) + rng.normal(0, 1e-4, (3, n))
+    if kind == "plane_lattice":
+        k = int(np.ceil(np.sqrt(n)))
+        u, v = np.meshgrid(np.arange(k), np.arange(k))
+        return np.stack([u.ravel()[:n] * 0.01, v.ravel()[:n] * 0.01, np.full(n, 2.0)])
+    if kind == "duplicates":
+        base = rng.uniform(-1, 1, (3, max(n // 7, 1)))
+        return base[:, rng.integers(0, base.shape[1], n)]
+    if kind == "tiny":
+        return rng.uniform(-1, 1, (3, n)) * 1e-6
+    return rng.uniform(-1, 1, (3, n)) * 1e4  # "huge"
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_fuzz_three_kernels_agree(ctx, seed):
+    """Random shapes, sizes and offsets: exact, filtered and pruned kernels must return the
+    same bits, on the first sweep and after the source has moved (seeded sweeps)."""
+    rng = np.random.default_rng(1000 + seed)
+    kinds = ["uniform", "clusters", "line", "plane_lattice", "duplicates", "tiny", "huge"]
+    kt, ks = kinds[seed % len(kinds)], kinds[(seed * 3 + 1) % len(kinds)]
+    nt, nq = int(rng.integers(1, 40000)), int(rng.integers(1, 30000))
+    off = rng.uniform(-10, 10, (3, 1))
+    tgt = (_fuzz_cloud(rng, nt, kt) + off).astype(np.float32)
+    src = (_fuzz_cloud(rng, nq, ks) + off + rng.normal(0, 0.01, (3, 1))).astype(np.float32)
+    if seed % 4 == 0:  # shuffle: no spatial order in the input
+        tgt = tgt[:, rng.permutation(nt)]
+    ctx.set_target(tgt)
+    ctx.set_source(src)
+    for sweep in range(3):
+        res = []
+        for mode in (binding.NN_EXACT, binding.NN_FILTERED, binding.NN_PRUNED, binding.NN_PRUNED):
+            res.append(ctx.nn(mode))  # the second pruned sweep is seeded by the first one's Morton-ordered matches
+        for r in res[1:]:
+            assert np.array_equal(res[0][0], r[0]), (kt, ks, nt, nq, sweep)
+            assert np.array_equal(res[0][1].view(np.uint32), r[1].view(np.uint32)), (kt, ks, nt, nq, sweep)
+        assert np.array_equal(ctx.pair_distance(src, tgt[:, res[0][0]]).view(np.uint32), res[0][1].view(np.uint32)) or sweep
+        R = synth.rot_xyz_deg(*rng.uniform(-1, 1, 3)).astype(np.float32)
+        ctx.transform_source(R, rng.normal(0, 0.01, 3).astype(np.float32))
+
+
+def test_non_finite_inputs_do_not_fault(ctx):
+    """Coordinates are expected to be finite (they come from uint16 depth); NaN/inf must
+    not hang or fault a kernel, and finite queries against finite targets stay exact."""
+    rng = np.random.default_rng(77)
+    tgt = rng.uniform(-2, 2, (3, 5000)).astype(np.float32)
+    src = rng.uniform(-2, 2, (3, 3000)).astype(np.float32)
+    src[0, 5] = np.nan
+    src[1, 700] = np.inf
+    src[2, 2999] = -np.inf
+    ctx.set_target(tgt)
+    ctx.set_source(src)
+    ok = np.ones(3000, bool)
+    ok[[5, 700, 2999]] = False
+    ie, de = ctx.nn(binding.NN_EXACT)
+    for mode in (binding.NN_FILTERED, binding.NN_PRUNED):
+        ctx.reset_source()
+        i2, d2 = ctx.nn(mode)
+        assert np.array_equal(ie[ok], i2[ok]) and np.array_equal(de[ok], d2[ok])
+        assert not np.isfinite(d2[~ok]).any()
+    T, st, rc = ctx.align(max_iterations=3, fixed_iterations=1, solve=binding.SOLVE_KABSCH)
+    assert st.final_pairs == 2997
