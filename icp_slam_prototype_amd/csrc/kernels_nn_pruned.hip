@@ -239,31 +239,34 @@ __global__ __launch_bounds__(64) void nn_pruned_kernel(
         while (s < nsl && !survives(s)) ++s;
         return s;
       };
-      float px0, px1, py0, py1, pz0, pz1;
-      auto load = [&](int s) {
-        const int o = sub_list[s] * NN_SUB + lane;
-        px0 = txp[o];
-        px1 = txp[o + 64];
-        py0 = typ[o];
-        py1 = typ[o + 64];
-        pz0 = tzp[o];
-        pz1 = tzp[o + 64];
+      // two register sets (A, B) in ping-pong: while candidate c is scanned the loads of c+1
+      // AND c+2 are in flight, so each has two scans of time to land
+      struct Regs {
+        float x0, x1, y0, y1, z0, z1;
       };
-      int cur = recheck ? next_surviving(0) : 0;
-      if (cur < nsl) load(cur);
-      while (cur < nsl) {
+      auto load = [&](Regs& r, int s) {
+        const int o = sub_list[s] * NN_SUB + lane;
+        r.x0 = txp[o];
+        r.x1 = txp[o + 64];
+        r.y0 = typ[o];
+        r.y1 = typ[o + 64];
+        r.z0 = tzp[o];
+        r.z1 = tzp[o + 64];
+      };
+      auto scan = [&](const Regs& r, int c) {
         __syncthreads();  // previous sub-tile fully consumed
-        stage[0][lane] = px0;
-        stage[0][64 + lane] = px1;
-        stage[1][lane] = py0;
-        stage[1][64 + lane] = py1;
-        stage[2][lane] = pz0;
-        stage[2][64 + lane] = pz1;
+        stage[0][lane] = r.x0;
+        stage[0][64 + lane] = r.x1;
+        stage[1][lane] = r.y0;
+        stage[1][64 + lane] = r.y1;
+        stage[2][lane] = r.z0;
+        stage[2][64 + lane] = r.z1;
         __syncthreads();
-        int nxt = recheck ? next_surviving(cur + 1) : cur + 1;  // judged with the thresholds before this scan
-        if (nxt < nsl) load(nxt);                                // in flight during the scan
-        const int jbase = sub_list[cur] * NN_SUB + slice * SLICE;
+      };
+      auto consume = [&](int c) {
+        const int jbase = sub_list[c] * NN_SUB + slice * SLICE;
         NP_COUNT(7, 1);  // sub-tiles scanned
+        const float Told = T[0];
 #pragma unroll 2
         for (int g = 0; g < SLICE; g += NNF_G) {
           const int o = slice * SLICE + g;
@@ -282,16 +285,32 @@ __global__ __launch_bounds__(64) void nn_pruned_kernel(
           if (__builtin_amdgcn_ballot_w64(m[0] <= T[0]) != 0)
             group_exact_lanes<1>(qx, qy, qz, X, Y, Z, e, jbase + g, tperm, bd, bj, T);
         }
-        if (S > 1) {  // the S lanes of a query share the tightest threshold
+        // the S lanes of a query share the tightest threshold (only when one changed)
+        if (S > 1 && __builtin_amdgcn_ballot_w64(T[0] != Told) != 0) {
 #pragma unroll
           for (int m = NQ; m < 64; m <<= 1) T[0] = __builtin_fminf(T[0], __shfl_xor(T[0], m, 64));
         }
-        // the prefetched candidate was judged before this scan tightened the thresholds
-        if (recheck && nxt < nsl && !survives(nxt)) {
-          nxt = next_surviving(nxt + 1);
-          if (nxt < nsl) load(nxt);
-        }
-        cur = nxt;
+      };
+      // candidate order: as listed, or (first sweep) each judged against the thresholds current
+      // at the time its loads are issued
+      auto next_cand = [&](int s) -> int { return recheck ? next_surviving(s) : s; };
+      Regs A, B;
+      int c0 = next_cand(0);
+      if (c0 < nsl) load(A, c0);
+      int c1 = c0 < nsl ? next_cand(c0 + 1) : nsl;
+      if (c1 < nsl) load(B, c1);
+      while (c0 < nsl) {
+        scan(A, c0);  // stage A
+        const int c2 = c1 < nsl ? next_cand(c1 + 1) : nsl;
+        if (c2 < nsl) load(A, c2);
+        consume(c0);
+        if (c1 >= nsl) break;
+        scan(B, c1);  // stage B
+        const int c3 = c2 < nsl ? next_cand(c2 + 1) : nsl;
+        if (c3 < nsl) load(B, c3);
+        consume(c1);
+        c0 = c2;
+        c1 = c3;
       }
     }
   }
