@@ -734,3 +734,17 @@ def test_non_finite_inputs_do_not_fault(ctx):
         assert not np.isfinite(d2[~ok]).any()
     T, st, rc = ctx.align(max_iterations=3, fixed_iterations=1, solve=binding.SOLVE_KABSCH)
     assert st.final_pairs == 2997
+
+
+def test_config5_full_size_one_sweep(ctx):
+    """BASELINE config 5 at full size, 10^6 x 10^6 unordered points: one sweep of the exact
+    kernel (10^12 pair evaluations, ~0.6 s) against the pruned kernel, bit for bit."""
+    p = synth.dense_pair(1_000_000, seed=5)
+    ctx.set_target(p["target"])
+    ctx.set_source(p["source"])
+    ie, de = ctx.nn(binding.NN_EXACT)
+    ctx.reset_source()
+    ip, dp = ctx.nn(binding.NN_PRUNED)
+    assert np.array_equal(ie, ip) and np.array_equal(de.view(np.uint32), dp.view(np.uint32))
+    sums, cnt = ctx.reduce(0.75)
+    assert cnt == 1_000_000
