@@ -342,6 +342,7 @@ void launch_nn_pruned(const NnArgs& a, const nn_key_t* seed_m, nn_key_t* best_m,
     case 1: ICPK_LAUNCH(1); break;
     case 2: ICPK_LAUNCH(2); break;
     case 8: ICPK_LAUNCH(8); break;
+    case 16: ICPK_LAUNCH(16); break;
     default: ICPK_LAUNCH(4); break;
   }
 #undef ICPK_LAUNCH
