@@ -748,3 +748,33 @@ def test_config5_full_size_one_sweep(ctx):
     assert np.array_equal(ie, ip) and np.array_equal(de.view(np.uint32), dp.view(np.uint32))
     sums, cnt = ctx.reduce(0.75)
     assert cnt == 1_000_000
+
+
+def test_golden_fixture_on_device(ctx):
+    """The committed fixture (tests/golden/oracle_regression.npz) reproduced by the HIP path
+    without calling the oracle at run time."""
+    import os
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "oracle_regression.npz"))
+    p = synth.lattice_wall(30, 40)
+    ctx.set_target(p["target"])
+    ctx.set_source(p["source"])
+    idx, dist = ctx.nn()
+    assert np.array_equal(idx, g["f1_lattice_idx"]) and np.array_equal(dist, g["f1_lattice_dist"])
+    q = synth.frustum_pair(1200, seed=1)
+    src, tgt = q["source"] + np.float32(5), q["target"] + np.float32(5)
+    ctx.set_target(tgt)
+    ctx.set_source(src)
+    idx, dist = ctx.nn()
+    assert np.array_equal(idx, g["f1_frustum_idx"]) and np.array_equal(dist, g["f1_frustum_dist"])
+    sums, _ = ctx.reduce(0.75)
+    assert np.array_equal(sums, g["f2_sums"])
+    T, st, _ = ctx.align(max_iterations=8, threshold=0.0, solve=binding.SOLVE_REFERENCE)
+    assert np.array_equal(T, g["f3_T"])
+    tr = ctx.get_trace()
+    assert np.array_equal(np.stack([t["R"] for t in tr]), g["f3_R"])
+    assert np.array_equal(np.stack([t["t"] for t in tr]), g["f3_t"])
+    T, st, _ = ctx.align(max_iterations=8, threshold=0.0, solve=binding.SOLVE_KABSCH)
+    assert np.array_equal(T, g["f3_kabsch_T"])
+    assert np.array_equal(binding.make_rotation_matrix(10, 20, 30), g["f5_rot_10_20_30"])
+    assert np.array_equal(binding.quaternion_to_euler(binding.matrix_to_quaternion(g["f5_rot_10_20_30"])), g["f5_euler"])

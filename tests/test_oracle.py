@@ -467,3 +467,31 @@ def test_align_point_to_plane_converges_config3_small(oracle):
         assert r["status"] == 0 and r["iterations"] == 20
     assert errs[2][0] < 2e-3 and errs[2][1] < 5e-3
     assert errs[2][0] < errs[1][0] / 5
+
+
+def test_oracle_regression_fixture(oracle):
+    """The oracle has not drifted since tests/golden/oracle_regression.npz was written
+    (see make_oracle_regression.py: oracle-generated, NOT reference-pinned)."""
+    g = np.load(os.path.join(GOLD, "oracle_regression.npz"))
+    p = synth.lattice_wall(30, 40)
+    idx, dist = oracle.nn_bruteforce(p["source"], p["target"])
+    assert np.array_equal(idx, g["f1_lattice_idx"]) and np.array_equal(dist, g["f1_lattice_dist"])
+    q = synth.frustum_pair(1200, seed=1)
+    src, tgt = q["source"] + np.float32(5), q["target"] + np.float32(5)
+    idx, dist = oracle.nn_bruteforce(src, tgt)
+    assert np.array_equal(idx, g["f1_frustum_idx"]) and np.array_equal(dist, g["f1_frustum_dist"])
+    assert np.array_equal(oracle.calculate_offset_seq(src, tgt, idx, dist, 0.75)[0], g["f2_offset"])
+    assert oracle.mse_seq(dist, 0.75) == g["f2_mse"][0]
+    assert np.array_equal(oracle.cross_moment_seq(src, tgt, idx, dist, 0.75)[0], g["f2_moment"])
+    assert np.array_equal(oracle.sums_canonical(src, tgt, idx, dist, 0.75)[0], g["f2_sums"])
+    r = oracle.align(src, tgt, max_iterations=8, threshold=0.0, solve=0, sum_order=1)
+    assert np.array_equal(r["T"], g["f3_T"])
+    assert np.array_equal(np.stack([t["R"] for t in r["trace"]]), g["f3_R"])
+    assert np.array_equal(np.stack([t["t"] for t in r["trace"]]), g["f3_t"])
+    assert np.array_equal(np.array([t["mse"] for t in r["trace"]], np.float32), g["f3_mse"])
+    assert np.array_equal(np.array([t["n_pairs"] for t in r["trace"]], np.int32), g["f3_pairs"])
+    assert np.array_equal(oracle.align(src, tgt, max_iterations=8, threshold=0.0, solve=1, sum_order=1)["T"], g["f3_kabsch_T"])
+    assert np.array_equal(oracle.make_rotation_matrix(0, 5, 0), g["f5_rot_0_5_0"])
+    assert np.array_equal(oracle.make_rotation_matrix(10, 20, 30), g["f5_rot_10_20_30"])
+    assert np.array_equal(oracle.quaternion_from_matrix(g["f5_rot_10_20_30"]), g["f5_quat"])
+    assert np.array_equal(oracle.to_euler(g["f5_quat"]), g["f5_euler"])
