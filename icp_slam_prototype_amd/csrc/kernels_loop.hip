@@ -82,14 +82,19 @@ template <int NS>
 __global__ __launch_bounds__(256) void loop_step_kernel(const double* __restrict__ partial,
                                                         const int* __restrict__ pcount, int nblocks,
                                                         LoopState* __restrict__ st, int stats_only) {
-  if (st->done) return;
-  if (st->stop_after_transform) {  // the fallback motion has been applied by the previous transform
-    if (threadIdx.x == 0) st->done = 1;
-    return;
-  }
+  // the control words are fetched together with the partial sums (independent loads in
+  // flight at once) and only then acted upon
+  const int done = st->done, stop_after = st->stop_after_transform, i = st->iterations;
+  const int max_iterations = st->max_iterations, min_pairs = st->min_pairs, fixed = st->fixed_iterations;
+  const float threshold = st->threshold;
   double sums[NS];
   long long npairs = 0;
   tree_stage2<NS>(partial, pcount, nblocks, sums, npairs);
+  if (done) return;
+  if (stop_after) {  // the fallback motion has been applied by the previous transform
+    if (threadIdx.x == 0) st->done = 1;
+    return;
+  }
   if (threadIdx.x != 0) return;
 
   // statistics of the sweep just reduced (icp.cpp:622-638 from the double sum)
@@ -102,12 +107,11 @@ __global__ __launch_bounds__(256) void loop_step_kernel(const double* __restrict
   st->mse = mse;
   if (stats_only) return;
 
-  const int i = st->iterations;
-  if (!((st->fixed_iterations || mse > st->threshold) && i < st->max_iterations)) {  // icp.cpp:155
+  if (!((fixed || mse > threshold) && i < max_iterations)) {  // icp.cpp:155
     st->done = 1;
     return;
   }
-  if (npairs < st->min_pairs) {  // icp.cpp:163-182
+  if (npairs < min_pairs) {  // icp.cpp:163-182
     for (int k = 0; k < 9; ++k) st->rt.R[k] = st->last_rotation[k];
     for (int k = 0; k < 3; ++k) {
       st->rt.t[k] = st->last_translation[k];
