@@ -778,3 +778,24 @@ def test_golden_fixture_on_device(ctx):
     assert np.array_equal(T, g["f3_kabsch_T"])
     assert np.array_equal(binding.make_rotation_matrix(10, 20, 30), g["f5_rot_10_20_30"])
     assert np.array_equal(binding.quaternion_to_euler(binding.matrix_to_quaternion(g["f5_rot_10_20_30"])), g["f5_euler"])
+
+
+@pytest.mark.parametrize("nq,nt", [(500_000, 300), (300, 500_000), (200_000, 1), (1, 200_000), (70_000, 130_000)])
+def test_lopsided_sizes_exact_vs_pruned(ctx, nq, nt):
+    rng = np.random.default_rng(nq + 3 * nt)
+    tgt = (rng.uniform(-2, 2, (3, nt)) + 5).astype(np.float32)
+    src = (rng.uniform(-2, 2, (3, nq)) + 5).astype(np.float32)
+    ctx.set_target(tgt)
+    ctx.set_source(src)
+    ie, de = ctx.nn(binding.NN_EXACT)
+    ctx.reset_source()
+    i_f, d_f = ctx.nn(binding.NN_FILTERED)
+    ctx.reset_source()
+    ip, dp = ctx.nn(binding.NN_PRUNED)
+    ip2, dp2 = ctx.nn(binding.NN_PRUNED)  # seeded re-sweep
+    for i2, d2 in ((i_f, d_f), (ip, dp), (ip2, dp2)):
+        assert np.array_equal(ie, i2) and np.array_equal(de.view(np.uint32), d2.view(np.uint32))
+    T1, s1, _ = ctx.align(max_iterations=2, fixed_iterations=1, solve=binding.SOLVE_KABSCH)
+    T2, s2, _ = ctx.align(max_iterations=2, fixed_iterations=1, solve=binding.SOLVE_KABSCH, nn_mode=binding.NN_EXACT,
+                          host_loop=1)
+    assert np.array_equal(T1, T2) and s1.final_pairs == s2.final_pairs
