@@ -79,3 +79,104 @@ def align_frame_batch(make_source, n_frames, target_on_rank0, align_fn, device, 
         T_local[k] = T
         S_local[k] = (it, status, pairs, mse)
     return gather_results(T_local, S_local, n_frames, device, dist)
+
+
+# ---------------------------------------------------------------------------------------
+# Query-sharded alignment of ONE large pair ("single huge pair"): the target
+# is broadcast once, every rank keeps Nq/G queries, and the only per-iteration exchange is
+# one all-reduce of 19 doubles + the pair count (152 + 8 bytes: pure latency); the 3x3
+# solve is replicated on every rank, so all ranks apply the same transform.
+# ---------------------------------------------------------------------------------------
+class ContextSteps:
+    """The three steps of an iteration on a C-ABI context (icpk_nn / icpk_reduce /
+    icpk_transform_source)."""
+
+    def __init__(self, ctx, nn_mode=None):
+        from . import binding
+
+        self.ctx = ctx
+        self.nn_mode = binding.NN_PRUNED if nn_mode is None else nn_mode
+
+    def nn(self):
+        self.ctx.nn(self.nn_mode, fetch=False)
+
+    def reduce(self, max_dist):
+        return self.ctx.reduce(max_dist)
+
+    def transform(self, R, t):
+        self.ctx.transform_source(R, t)
+
+
+def _mul3f(A, B):
+    A = np.asarray(A, np.float64)
+    B = np.asarray(B, np.float64)
+    return ((A[:, 0:1] * B[0:1, :] + A[:, 1:2] * B[1:2, :]) + A[:, 2:3] * B[2:3, :]).astype(np.float32)
+
+
+def _inv3f(R):
+    a, b, c, d, e, f, g, h, i = np.asarray(R, np.float64).reshape(9)
+    det = a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g)
+    s = 1.0 / det
+    return np.array([(e * i - f * h) * s, (c * h - b * i) * s, (b * f - c * e) * s,
+                     (f * g - d * i) * s, (a * i - c * g) * s, (c * d - a * f) * s,
+                     (d * h - e * g) * s, (b * g - a * h) * s, (a * e - b * d) * s]).astype(np.float32).reshape(3, 3)
+
+
+def align_query_sharded(steps, dist, device, max_iterations=16, threshold=1e-4, max_nn_dist=0.75, min_pairs=3,
+                        solve=1, fixed_iterations=False):
+    """Runs the ICP loop on this rank's slice of the queries (already uploaded as the
+    source of `steps`, target already set on every rank).  solve: 0 reference flavour
+    (icp.cpp:199-246), 1 Kabsch (rigid_transform_3D.py).  Returns (T (4,4) float32,
+    iterations, total pairs, mse) -- identical on every rank."""
+    import torch
+
+    from . import binding
+
+    def global_sums():
+        sums, cnt = steps.reduce(max_nn_dist)
+        buf = torch.zeros(20, dtype=torch.float64, device=device)
+        buf[:19] = torch.as_tensor(sums)
+        buf[19] = float(cnt)
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM)  # RCCL all-reduce: 160 bytes per iteration
+        out = buf.cpu().numpy()
+        return out[:19], int(round(out[19]))
+
+    def mse_of(sums, n):
+        if n <= 0:
+            return np.float32(0)
+        m = np.float32(sums[12] / float(n))
+        return np.float32(np.float64(m) * np.float64(m))
+
+    steps.nn()
+    sums, n = global_sums()
+    mse = mse_of(sums, n)
+    Trot = np.eye(3, dtype=np.float32)
+    offset = np.zeros(3, np.float32)
+    Tk = np.eye(4)[:3].copy()
+    i = 0
+    while (fixed_iterations or mse > np.float32(threshold)) and i < max_iterations:
+        if n < min_pairs:
+            break
+        if solve == 0:
+            R = binding.solve_reference(sums[:9].astype(np.float32).reshape(3, 3))
+            Trot = R.copy() if i == 0 else _mul3f(R, Trot)
+            offset = (sums[9:12] / float(n)).astype(np.float32)
+            steps.transform(_inv3f(R), -offset)
+        else:
+            Rd, td = binding.solve_kabsch(n, sums[13:16], sums[16:19], sums[:9].reshape(3, 3).T)
+            Rf, tf = Rd.astype(np.float32), td.astype(np.float32)
+            steps.transform(Rf, tf)
+            Tn = Rf.astype(np.float64) @ Tk
+            Tn[:, 3] += tf.astype(np.float64)
+            Tk = Tn
+        steps.nn()
+        sums, n = global_sums()
+        mse = mse_of(sums, n)
+        i += 1
+    T = np.eye(4, dtype=np.float32)
+    if solve == 0:
+        T[:3, :3] = Trot
+        T[:3, 3] = offset
+    else:
+        T[:3, :] = Tk.astype(np.float32)
+    return T, i, n, mse

@@ -82,3 +82,70 @@ def test_frame_batch_two_ranks_matches_serial(n_frames, oracle):
             assert np.array_equal(T[i], r["T"]), (rank, i)
             assert S[i, 0] == 3 and S[i, 1] == 0 and S[i, 2] == r["final_pairs"]
     assert np.array_equal(res[0][1], res[1][1])  # every rank holds the same gathered result
+
+
+class _OracleSteps:
+    """CPU stand-in for batch.ContextSteps (test only): the oracle does the three steps."""
+
+    def __init__(self, oracle, src, tgt):
+        self.o, self.src, self.tgt = oracle, src.copy(), tgt
+        self.idx = self.dist = None
+
+    def nn(self):
+        self.idx, self.dist = self.o.nn_bruteforce(self.src, self.tgt)
+
+    def reduce(self, max_dist):
+        return self.o.sums_canonical(self.src, self.tgt, self.idx, self.dist, max_dist)
+
+    def transform(self, R, t):
+        self.src = self.o.transform_points(self.src, R, t)
+
+
+def _sharded_worker(rank, world, port, solve, q):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+
+    from icp_slam_prototype_amd import batch, build, synth
+    from oracle import icp_oracle as o
+
+    build.build()  # the host solve comes from libicpk.so (no device work)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    p = synth.frustum_pair(1500, seed=6, rot_deg=(0, 2, 0), shift=(0.01, 0, 0))
+    tgt = batch.broadcast_cloud(p["target"] + np.float32(5) if rank == 0 else None, 0, torch.device("cpu"), dist).numpy()
+    s, c = batch.partition(1500, world, rank)
+    steps = _OracleSteps(o, np.ascontiguousarray((p["source"] + np.float32(5))[:, s:s + c]), tgt)
+    T, it, n, mse = batch.align_query_sharded(steps, dist, torch.device("cpu"), max_iterations=6, solve=solve,
+                                              fixed_iterations=True)
+    q.put((rank, T, it, n, float(mse)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("solve", [0, 1])
+def test_query_sharded_alignment_two_ranks(solve, oracle):
+    """One pair, queries split over 2 ranks, one all-reduce of the 19 sums per iteration:
+    same transform as the single-process loop up to the summation order across ranks."""
+    import torch.multiprocessing as mp
+
+    from icp_slam_prototype_amd import synth
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, solve, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    pr = synth.frustum_pair(1500, seed=6, rot_deg=(0, 2, 0), shift=(0.01, 0, 0))
+    ref = oracle.align(pr["source"] + np.float32(5), pr["target"] + np.float32(5), max_iterations=6, solve=solve,
+                       sum_order=1, fixed_iterations=True)
+    assert np.array_equal(res[0][1], res[1][1])  # replicated solve: every rank holds the same T
+    assert res[0][2] == ref["iterations"] == 6 and res[0][3] == ref["final_pairs"]
+    assert np.linalg.norm(res[0][1].astype(np.float64) - ref["T"].astype(np.float64)) < 1e-5
