@@ -48,6 +48,10 @@ def parse():
     ap.add_argument("--solve", default="reference", choices=["reference", "kabsch", "p2l"])
     ap.add_argument("--nn-mode", default="pruned", choices=["exact", "filtered", "pruned"],
                     help="all three give bit-identical results; pruned is the product default")
+    ap.add_argument("--shard", default="frames", choices=["frames", "queries"],
+                    help="N>1: 'frames' = one frame pair per rank, no per-iteration collective (default, weak "
+                         "scaling); 'queries' = ONE pair, queries split over ranks, one 160-byte all-reduce per "
+                         "iteration (strong scaling; SURVEY.md 8e alternative)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=32768, help="queries in the CPU baseline sample")
     return ap.parse_args()
@@ -129,6 +133,9 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    if args.shard == "queries" and world > 1:
+        return bench_query_sharded(args, rank, world, dev, cdev, gpu_index, dist)
 
     # ---- workload: own source frame per rank; key frame (target) from rank 0 ----
     base_seed = 2
@@ -285,6 +292,64 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def bench_query_sharded(args, rank, world, dev, cdev, gpu_index, dist):
+    """One frame pair, queries split over the ranks (batch.align_query_sharded): per iteration
+    every rank runs K1/K2 on its slice, then ONE all-reduce of 19 sums + count (RCCL, 160 bytes)
+    and a replicated 3x3 solve.  The loop is host-driven (the collective sits between K2 and
+    the solve), so this mode pays one stream sync + one collective latency per iteration."""
+    import torch
+
+    from icp_slam_prototype_amd import batch, binding
+
+    w = make_workload(args.workload, 2)
+    tgt = batch.broadcast_cloud(w["target"] if rank == 0 else None, 0, cdev, dist).cpu().numpy()
+    nq_total = w["source"].shape[1]
+    s0, cnt = batch.partition(nq_total, world, rank)
+    src = np.ascontiguousarray(w["source"][:, s0:s0 + cnt])
+    ctx = binding.Context(gpu_index)
+    ctx.set_target(tgt)
+    ctx.set_source(src)
+    steps = batch.ContextSteps(ctx, {"exact": binding.NN_EXACT, "filtered": binding.NN_FILTERED,
+                                     "pruned": binding.NN_PRUNED}[args.nn_mode])
+    solve = {"reference": 0, "kabsch": 1}.get(args.solve)
+    if solve is None:
+        raise SystemExit("--shard queries supports --solve reference|kabsch")
+
+    def one_step():
+        ctx.reset_source()
+        return batch.align_query_sharded(steps, dist, cdev, max_iterations=args.iters, solve=solve,
+                                         fixed_iterations=True)
+
+    for _ in range(args.warmup):
+        one_step()
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    iters = 0
+    for _ in range(args.steps):
+        iters += one_step()[1]
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=cdev)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    elapsed = float(tt.item())
+    if rank == 0:
+        print(json.dumps({
+            "metric": "ICP iterations/sec + NN Mpoints/sec at 307k-pt Kinect cloud, 1/2/4/8 GPU",
+            "value": iters / elapsed, "unit": "iter/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32 filter + f64 exact pair arithmetic, f64 reductions", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {nq_total} source x {tgt.shape[1]} target points, {args.iters} "
+                                   f"fixed ICP iterations per step, solve={args.solve}, nn={args.nn_mode}",
+                       "parallelism": f"query-sharded x{world}, 1 all-reduce(160 B)/iteration"},
+            "nn_mpoints_per_s": iters * nq_total / elapsed / 1e6}))
+    ctx.close()
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 if __name__ == "__main__":
