@@ -48,6 +48,7 @@ class Params(C.Structure):
         ("last_rotation", C.c_float * 9),
         ("last_translation", C.c_float * 3),
         ("host_loop", C.c_int32),
+        ("profile_stride", C.c_int32),
     ]
 
 
@@ -58,7 +59,7 @@ class Stats(C.Structure):
         ("final_pairs", C.c_int32),
         ("final_mse", C.c_float),
         ("nn_launches", C.c_int32),
-        ("reserved", C.c_int32),
+        ("nn_timed_launches", C.c_int32),
         ("nn_ms_total", C.c_float),
         ("reduce_ms_total", C.c_float),
         ("transform_ms_total", C.c_float),

@@ -765,9 +765,12 @@ static int align_device_loop(icpk_ctx* ctx, const icpk_params* p, float T_out[16
   ctx->st_active = ctx->st_dev;
 
   std::vector<nn_key_t*> best_of_sweep;
+  int nsweep = 0;
   auto sweep = [&]() -> int {
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (prof) {  // two events tightly around the K1 launch
+    const int nth = nsweep++;
+    if (prof && (prof_all || p->profile_stride <= 1 || nth % p->profile_stride == 0)) {
+      // two events tightly around the K1 launch
       e0 = get_event(ctx, nev);
       e1 = get_event(ctx, nev + 1);
       if (!e0 || !e1) return fail(ctx, ICPK_E_HIP, "hipEventCreate failed");
@@ -838,6 +841,7 @@ static int align_device_loop(icpk_ctx* ctx, const icpk_params* p, float T_out[16
     stats->final_pairs = (int32_t)h->pairs;
     stats->final_mse = h->mse;
     stats->nn_launches = k;
+    stats->nn_timed_launches = (int32_t)ev_nn.size();
     if (prof && nev >= 2) {
       auto span = [&](size_t a, size_t b) {
         float ms = 0.f;
@@ -919,6 +923,7 @@ int icpk_align(icpk_ctx* ctx, const icpk_params* p, float T_out[16], icpk_stats*
     return align_device_loop(ctx, p, T_out, stats);
 
   const bool prof = p->profile != 0;
+  const bool prof_all = p->profile >= 2;
   size_t nev = 0;
   std::vector<size_t> ev_nn, ev_red, ev_tr;  // indices of (start, stop) pairs
   auto stamp = [&](std::vector<size_t>* list) -> int {
@@ -937,9 +942,12 @@ int icpk_align(icpk_ctx* ctx, const icpk_params* p, float T_out[16], icpk_stats*
   int64_t npairs = 0;
   float mse = 0.f;
   int sweeps = 0;
+  int nsweep = 0;
   auto sweep = [&]() -> int {
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (prof) {  // two events tightly around the K1 launch
+    const int nth = nsweep++;
+    if (prof && (prof_all || p->profile_stride <= 1 || nth % p->profile_stride == 0)) {
+      // two events tightly around the K1 launch
       e0 = get_event(ctx, nev);
       e1 = get_event(ctx, nev + 1);
       if (!e0 || !e1) return fail(ctx, ICPK_E_HIP, "hipEventCreate failed");
@@ -1099,6 +1107,7 @@ int icpk_align(icpk_ctx* ctx, const icpk_params* p, float T_out[16], icpk_stats*
     stats->final_pairs = (int32_t)npairs;
     stats->final_mse = mse;
     stats->nn_launches = sweeps;
+    stats->nn_timed_launches = (int32_t)ev_nn.size();
     if (prof && nev >= 2) {
       auto span = [&](size_t a, size_t b) {
         float ms = 0.f;

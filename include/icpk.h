@@ -102,6 +102,8 @@ typedef struct icpk_params {
                                and the loop test / solve run on the device (no host round
                                trip per iteration); 1: the host drives each iteration and
                                solves (one 160-byte read-back per iteration).  Same results. */
+  int32_t profile_stride;   /* profile == 1 only: bracket every n-th NN launch (0, 1: every one);
+                               an event pair costs ~4 us of queue time, which a 40 us kernel notices */
 } icpk_params;
 
 typedef struct icpk_stats {
@@ -110,13 +112,13 @@ typedef struct icpk_stats {
   int32_t final_pairs; /* associations after the last sweep                       */
   float final_mse;     /* meanSquareError of the last sweep (icp.cpp:264)         */
   int32_t nn_launches; /* NN sweeps launched (= iterations + 1)                   */
-  int32_t reserved;
+  int32_t nn_timed_launches; /* NN launches bracketed by events (see profile_stride)    */
   /* device times measured with HIP events on the context's stream; filled only
    * when params.profile != 0 */
-  float nn_ms_total;        /* sum over sweeps of the NN kernel(s)                */
+  float nn_ms_total;        /* sum over the nn_timed_launches bracketed NN kernels */
   float reduce_ms_total;    /* association reduce kernels                         */
   float transform_ms_total; /* point transform kernels                            */
-  float total_ms;           /* first launch to last completion                    */
+  float total_ms;           /* first to last recorded event                       */
 } icpk_stats;
 
 /* One frame pair for icpk_align_batch (host pointers, SoA). */

@@ -36,7 +36,7 @@ def test_library_exports_every_declared_symbol(lib):
 
 
 def test_struct_layouts_match_header(lib):
-    assert C.sizeof(binding.Params) == 8 * 4 + 12 * 4 + 4
+    assert C.sizeof(binding.Params) == 8 * 4 + 12 * 4 + 4 + 4
     assert C.sizeof(binding.Stats) == 6 * 4 + 4 * 4
     p = binding.default_params()
     assert (p.max_iterations, p.min_pairs, p.solve, p.nn_mode) == (16, 3, 0, binding.NN_PRUNED)

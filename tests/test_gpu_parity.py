@@ -297,6 +297,11 @@ def test_profile_stats(ctx):
         assert st.total_ms >= st.nn_ms_total
     T, st, rc = ctx.align(max_iterations=3, fixed_iterations=1, profile=1, solve=binding.SOLVE_KABSCH)
     assert st.nn_launches == 4 and st.nn_ms_total > 0 and st.reduce_ms_total == 0 and st.total_ms >= st.nn_ms_total
+    assert st.nn_timed_launches == 4
+    # profile_stride: only every n-th NN launch carries an event pair
+    T2, st2, _ = ctx.align(max_iterations=9, fixed_iterations=1, profile=1, profile_stride=4,
+                           solve=binding.SOLVE_KABSCH)
+    assert st2.nn_launches == 10 and st2.nn_timed_launches == 3 and st2.nn_ms_total > 0
 
 
 # -------------------------------------------------------------- backproject --
