@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--workload", default="kinect640x480_30pct",
                     choices=["kinect640x480_30pct", "kinect640x480_dense", "kinect_v2_512x424", "dense1m", "frustum10k"])
     ap.add_argument("--solve", default="reference", choices=["reference", "kabsch", "p2l"])
-    ap.add_argument("--nn-mode", default="pruned", choices=["exact", "filtered", "pruned"],
+    ap.add_argument("--nn-mode", default="pruned", choices=["exact", "filtered", "pruned", "grid"],
                     help="all three give bit-identical results; pruned is the product default")
     ap.add_argument("--shard", default="frames", choices=["frames", "queries"],
                     help="N>1: 'frames' = one frame pair per rank, no per-iteration collective (default, weak "
@@ -169,7 +169,7 @@ def main():
         max_nn_dist=0.3 if args.solve == "p2l" else 0.75,
         solve={"reference": binding.SOLVE_REFERENCE, "kabsch": binding.SOLVE_KABSCH,
                "p2l": binding.SOLVE_POINT_TO_PLANE}[args.solve],
-        nn_mode={"exact": binding.NN_EXACT, "filtered": binding.NN_FILTERED, "pruned": binding.NN_PRUNED}[args.nn_mode])
+        nn_mode={"exact": binding.NN_EXACT, "filtered": binding.NN_FILTERED, "pruned": binding.NN_PRUNED, "grid": binding.NN_GRID}[args.nn_mode])
 
     def sync_all():
         torch.cuda.synchronize()
@@ -244,7 +244,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": {"exact": "nn_exact_kernel", "filtered": "nn_filtered_kernel<2>",
-                                    "pruned": "nn_pruned_kernel<4>"}[args.nn_mode],
+                                    "pruned": "nn_pruned_kernel<4>", "grid": "nn_grid_kernel"}[args.nn_mode],
                          "avg_launch_ms": avg_nn_s * 1e3, "algorithmic_bytes_per_launch": alg_bytes,
                          "timing": f"two HIP events recorded on the kernel's own stream immediately around every 4th "
                                    f"K1 launch of the timed region ({nn_timed} of {nn_launches} launches; includes "
@@ -318,7 +318,7 @@ def bench_query_sharded(args, rank, world, dev, cdev, gpu_index, dist):
     ctx.set_target(tgt)
     ctx.set_source(src)
     steps = batch.ContextSteps(ctx, {"exact": binding.NN_EXACT, "filtered": binding.NN_FILTERED,
-                                     "pruned": binding.NN_PRUNED}[args.nn_mode])
+                                     "pruned": binding.NN_PRUNED, "grid": binding.NN_GRID}[args.nn_mode])
     solve = {"reference": 0, "kabsch": 1}.get(args.solve)
     if solve is None:
         raise SystemExit("--shard queries supports --solve reference|kabsch")

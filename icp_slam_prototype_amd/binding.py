@@ -19,7 +19,7 @@ SOLVE_REFERENCE, SOLVE_KABSCH, SOLVE_POINT_TO_PLANE = 0, 1, 2
 W_DEGENERATE = 2
 NORMALS_CROSS, NORMALS_REFERENCE = 0, 1
 NP2L = 28
-NN_EXACT, NN_FILTERED, NN_PRUNED = 0, 1, 2
+NN_EXACT, NN_FILTERED, NN_PRUNED, NN_GRID = 0, 1, 2, 3
 NSUM = 19
 
 # every symbol include/icpk.h declares (tests/test_abi.py checks the header against this list)

@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "icpk.h"
@@ -89,6 +90,21 @@ struct icpk_ctx {
   int target_blocks = 16384;
   int q_per_lane = 0;  // 0 = auto
   int slices = 0;      // pruned scan: lanes per query (0 = by cloud size)
+  // grid scan (ICPK_NN_GRID): cell table + AoS copy of the target sorted by cell
+  GridInfo* grid_info = nullptr;
+  float* grid_bounds = nullptr;
+  int* cell_start = nullptr;  // GRID_MAX_CELLS + 1
+  float4* t4 = nullptr;
+  int* grid_perm = nullptr;  // sorted position -> original index
+  float4* qm4 = nullptr;     // queries in Morton order (x, y, z, original index)
+  float4* sp_in = nullptr;   // seeds as points, query Morton order: read by the next grid sweep
+  float4* sp_out = nullptr;  // ... written by it
+  int qm4_cap = 0;
+  bool grid_chain = false;   // device loop only: the previous sweep was a grid sweep (qm4 / sp_in current)
+  int t4_cap = 0;
+  bool have_grid = false;  // grid matches tgt
+  float grid_ppc = 8.f;    // aimed-at targets per occupied cell
+  int grid_slices = 0;     // lanes per query (0 = by cloud size)
   std::string err;
   icpk_log_fn log_fn = nullptr;
   void* log_user = nullptr;
@@ -300,6 +316,40 @@ int prepare_pruned_target(icpk_ctx* ctx, NnBoxes& bx) {
   return ICPK_OK;
 }
 
+// cell table + cell-sorted AoS copy of the target for the grid scan (once per target cloud)
+int prepare_grid_target(icpk_ctx* ctx) {
+  const int nt = ctx->tgt.n;
+  if (!ctx->grid_info) ICPK_HIP(ctx, hipMalloc((void**)&ctx->grid_info, sizeof(GridInfo)));
+  if (!ctx->grid_bounds) ICPK_HIP(ctx, hipMalloc((void**)&ctx->grid_bounds, 6 * sizeof(float)));
+  if (!ctx->cell_start) ICPK_HIP(ctx, hipMalloc((void**)&ctx->cell_start, ((size_t)GRID_MAX_CELLS + 1) * sizeof(int)));
+  if (nt > ctx->t4_cap) {
+    if (ctx->t4) ICPK_HIP(ctx, hipFree(ctx->t4));
+    ctx->t4 = nullptr;
+    ctx->t4_cap = 0;
+    ICPK_HIP(ctx, hipMalloc((void**)&ctx->t4, ((size_t)round_up(nt, NN_TILE) + 64) * sizeof(float4)));
+    if (ctx->grid_perm) ICPK_HIP(ctx, hipFree(ctx->grid_perm));
+    ctx->grid_perm = nullptr;
+    ICPK_HIP(ctx, hipMalloc((void**)&ctx->grid_perm, ((size_t)round_up(nt, NN_TILE) + 64) * sizeof(int)));
+    ctx->t4_cap = round_up(nt, NN_TILE);
+    ctx->have_grid = false;
+  }
+  if (ctx->have_grid) return ICPK_OK;
+  int rc = ensure_sort_buffers(ctx, nt);
+  if (rc) return rc;
+  launch_grid_bounds(ctx->tgt.x(), ctx->tgt.y(), ctx->tgt.z(), nt, ctx->grid_bounds, ctx->stream);
+  launch_grid_info(ctx->grid_bounds, nt, ctx->grid_ppc, ctx->grid_info, ctx->stream);
+  unsigned* ka = ctx->sort_keys;
+  unsigned* kb = ctx->sort_keys + ctx->sort_cap;
+  launch_grid_cid(ctx->tgt.x(), ctx->tgt.y(), ctx->tgt.z(), nt, ctx->grid_info, ka, ctx->sort_vals, ctx->stream);
+  if (launch_sort_pairs(ctx->sort_temp, ctx->sort_temp_bytes, ka, kb, ctx->sort_vals, ctx->grid_perm, nt, ctx->stream) != 0)
+    return fail(ctx, ICPK_E_HIP, "rocprim::radix_sort_pairs failed");
+  launch_grid_gather(ctx->tgt.x(), ctx->tgt.y(), ctx->tgt.z(), ctx->grid_perm, nt, ctx->t4, ctx->stream);
+  launch_grid_starts(kb, nt, ctx->grid_info, ctx->cell_start, ctx->stream);
+  ICPK_HIP(ctx, hipGetLastError());
+  ctx->have_grid = true;
+  return ICPK_OK;
+}
+
 // enqueue one NN sweep (K1) over the working source; ev0/ev1 (optional) are recorded
 // immediately before/after the K1 launch itself, so that set-up kernels of a first sweep
 // (sort, seeding, fills) do not count as kernel time
@@ -308,7 +358,7 @@ int enqueue_nn(icpk_ctx* ctx, int nn_mode, hipEvent_t ev0 = nullptr, hipEvent_t 
     if (e) ICPK_HIP(ctx, hipEventRecord(e, ctx->stream));
     return ICPK_OK;
   };
-  if (nn_mode != ICPK_NN_EXACT && nn_mode != ICPK_NN_FILTERED && nn_mode != ICPK_NN_PRUNED)
+  if (nn_mode != ICPK_NN_EXACT && nn_mode != ICPK_NN_FILTERED && nn_mode != ICPK_NN_PRUNED && nn_mode != ICPK_NN_GRID)
     return fail(ctx, ICPK_E_ARG, "unknown nn_mode");
   const int nq = ctx->src.n;
   int rc = ensure_assoc(ctx, nq);
@@ -341,7 +391,7 @@ int enqueue_nn(icpk_ctx* ctx, int nn_mode, hipEvent_t ev0 = nullptr, hipEvent_t 
     if ((rc = mark(ev0))) return rc;
     launch_nn_exact(a, ctx->stream);
     if ((rc = mark(ev1))) return rc;
-  } else if (nn_mode == ICPK_NN_PRUNED) {
+  } else if (nn_mode == ICPK_NN_PRUNED || nn_mode == ICPK_NN_GRID) {
     if (round_up(nq, NN_TILE) > ctx->qperm_cap) {
       if (ctx->qperm) ICPK_HIP(ctx, hipFree(ctx->qperm));
       ctx->qperm = nullptr;
@@ -351,8 +401,12 @@ int enqueue_nn(icpk_ctx* ctx, int nn_mode, hipEvent_t ev0 = nullptr, hipEvent_t 
       ctx->have_qperm = false;
     }
     NnBoxes bx;
-    rc = prepare_pruned_target(ctx, bx);
+    rc = prepare_pruned_target(ctx, bx);  // Morton order and first-sweep seeds are shared with the grid scan
     if (rc) return rc;
+    if (nn_mode == ICPK_NN_GRID) {
+      rc = prepare_grid_target(ctx);
+      if (rc) return rc;
+    }
     bool new_order = false;
     if (!ctx->have_qperm || !ctx->have_seed) {
       // query order = Morton order of the source at its current pose (once per alignment);
@@ -387,6 +441,26 @@ int enqueue_nn(icpk_ctx* ctx, int nn_mode, hipEvent_t ev0 = nullptr, hipEvent_t 
     a.tz = ctx->sorted.z();
     a.tiles_per_chunk = ntiles;
     a.best = ctx->best;
+    if (nn_mode == ICPK_NN_GRID) {
+      if (nq > ctx->qm4_cap) {
+        for (float4** pp : {&ctx->qm4, &ctx->sp_in, &ctx->sp_out}) {
+          if (*pp) ICPK_HIP(ctx, hipFree(*pp));
+          *pp = nullptr;
+        }
+        ctx->qm4_cap = 0;
+        const size_t bytes = ((size_t)round_up(nq, NN_TILE) + 64) * sizeof(float4);
+        ICPK_HIP(ctx, hipMalloc((void**)&ctx->qm4, bytes));
+        ICPK_HIP(ctx, hipMalloc((void**)&ctx->sp_in, bytes));
+        ICPK_HIP(ctx, hipMalloc((void**)&ctx->sp_out, bytes));
+        ctx->qm4_cap = round_up(nq, NN_TILE);
+        ctx->grid_chain = false;
+      }
+      // inside a device loop the grid sweeps keep qm4 / the seed points current themselves;
+      // anywhere else the source may have been moved by other kernels: gather afresh
+      if (!(ctx->st_active && ctx->grid_chain))
+        launch_grid_query_points(ctx->src.x(), ctx->src.y(), ctx->src.z(), ctx->qperm, nq, ctx->seed_m, bx.ox, bx.oy,
+                                 bx.oz, ctx->qm4, ctx->sp_in, ctx->stream);
+    }
     if ((rc = mark(ev0))) return rc;
     // lanes per query: as many as keep the launch at <= ~10k waves (measured best: 16 at 10k
     // queries, 4 at 92k, 2 at 217k-307k, 1 at 10^6)
@@ -395,7 +469,20 @@ int enqueue_nn(icpk_ctx* ctx, int nn_mode, hipEvent_t ev0 = nullptr, hipEvent_t 
       slices = 16;
       while (slices > 1 && (long long)nq * slices / 64 > 10000) slices >>= 1;
     }
-    launch_nn_pruned(a, ctx->seed_m, ctx->best_m, bx, slices, recheck, ctx->st_active, ctx->stream);
+    if (nn_mode == ICPK_NN_GRID) {
+      int gs = ctx->grid_slices;
+      if (gs == 0) {
+        gs = 8;
+        while (gs > 1 && (long long)nq * gs / 64 > 12000) gs >>= 1;
+      }
+      launch_nn_grid(a, ctx->qm4, ctx->t4, ctx->cell_start, ctx->grid_info, bx.ox, bx.oy, bx.oz, ctx->sp_in,
+                     ctx->sp_out, ctx->best_m, gs, recheck, ctx->st_active, ctx->stream);
+      std::swap(ctx->sp_in, ctx->sp_out);
+      ctx->grid_chain = ctx->st_active != nullptr;
+    } else {
+      launch_nn_pruned(a, ctx->seed_m, ctx->best_m, bx, slices, recheck, ctx->st_active, ctx->stream);
+      ctx->grid_chain = false;
+    }
     if ((rc = mark(ev1))) return rc;
     ICPK_HIP(ctx, hipGetLastError());
     ctx->have_assoc = true;
@@ -524,6 +611,14 @@ int icpk_create(icpk_ctx** out, int device_id) {
     const int v = std::atoi(e);
     if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) ctx->slices = v;
   }
+  if (const char* e = std::getenv("ICPK_GRID_PPC")) {
+    const float v = (float)std::atof(e);
+    if (v > 0.f) ctx->grid_ppc = v;
+  }
+  if (const char* e = std::getenv("ICPK_GRID_SLICES")) {
+    const int v = std::atoi(e);
+    if (v == 1 || v == 2 || v == 4 || v == 8) ctx->grid_slices = v;
+  }
   if (const char* e = std::getenv("ICPK_NN_Q")) {
     const int v = std::atoi(e);
     if (v == 1 || v == 2) ctx->q_per_lane = v;
@@ -538,7 +633,7 @@ void icpk_destroy(icpk_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   for (hipEvent_t e : ctx->events) (void)hipEventDestroy(e);
-  void* dev[] = {ctx->best_m, ctx->seed_m, ctx->st_dev, ctx->sorted.base, ctx->tkeys, ctx->tperm, ctx->qperm, ctx->bounds, ctx->sort_keys, ctx->sort_vals, ctx->sort_temp,
+  void* dev[] = {ctx->qm4, ctx->sp_in, ctx->sp_out, ctx->grid_info, ctx->grid_bounds, ctx->cell_start, ctx->t4, ctx->grid_perm, ctx->best_m, ctx->seed_m, ctx->st_dev, ctx->sorted.base, ctx->tkeys, ctx->tperm, ctx->qperm, ctx->bounds, ctx->sort_keys, ctx->sort_vals, ctx->sort_temp,
                  ctx->nrm.base, ctx->boxes, ctx->dec.base, ctx->tgt.base, ctx->src0.base, ctx->src.base, ctx->best,      ctx->seed,     ctx->idx,
                  ctx->dist,     ctx->partial,   ctx->pcount,   ctx->red_out,   ctx->depth_dev, ctx->bp_counts};
   for (void* p : dev)
@@ -571,6 +666,8 @@ static int set_target_impl(icpk_ctx* ctx, const float* x, const float* y, const 
   ctx->have_assoc = false;
   ctx->have_dec = false;
   ctx->have_boxes = false;
+  ctx->have_grid = false;
+  ctx->have_grid = false;
   ctx->have_seed = false;
   ctx->have_normals = false;
   return ICPK_OK;
@@ -727,7 +824,7 @@ static int align_device_loop(icpk_ctx* ctx, const icpk_params* p, float T_out[16
   const bool prof = p->profile != 0;
   const bool prof_all = p->profile >= 2;  // 1: NN kernels only (2 events per sweep); 2: every stage
   const bool p2l = p->solve == ICPK_SOLVE_POINT_TO_PLANE;
-  const bool fused = p->nn_mode == ICPK_NN_PRUNED;  // K3 runs inside the pruned sweep
+  const bool fused = p->nn_mode == ICPK_NN_PRUNED || p->nn_mode == ICPK_NN_GRID;  // K3 runs inside the sweep
   const int nsum = p2l ? NP2L : NSUM;
   const int B = red_blocks(ctx->src.n);
   size_t nev = 0;
@@ -759,10 +856,12 @@ static int align_device_loop(icpk_ctx* ctx, const icpk_params* p, float T_out[16
     ~Guard() {
       c->stop = nullptr;
       c->st_active = nullptr;
+      c->grid_chain = false;
     }
   } guard{ctx};
   ctx->stop = &ctx->st_dev->done;
   ctx->st_active = ctx->st_dev;
+  ctx->grid_chain = false;
 
   std::vector<nn_key_t*> best_of_sweep;
   int nsweep = 0;
@@ -880,6 +979,7 @@ int icpk_transform_target(icpk_ctx* ctx, const float R[9], const float t[3]) {
   ctx->have_assoc = false;
   ctx->have_dec = false;
   ctx->have_boxes = false;
+  ctx->have_grid = false;
   ctx->have_seed = false;
   ICPK_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return ICPK_OK;
@@ -1198,7 +1298,7 @@ static int backproject_impl(icpk_ctx* ctx, const uint16_t* depth, int32_t rows, 
   ctx->have_seed = false;
   ctx->have_qperm = false;
   if (which == 1) {
-    ctx->have_dec = ctx->have_boxes = false;
+    ctx->have_dec = ctx->have_boxes = ctx->have_grid = false;
     ctx->have_normals = normals_mode >= 0;
     if (ctx->have_normals) ctx->nrm.n = n;
   }

@@ -97,6 +97,28 @@ void launch_tile_boxes(const float* x, const float* y, const float* z, int n, in
                        hipStream_t s);
 void launch_decimate(const float* x, const float* y, const float* z, int n, int stride, float* ox, float* oy, float* oz,
                      int n_out_pad, hipStream_t s);
+// kernels_grid.hip: uniform grid over the target (ICPK_NN_GRID)
+constexpr int GRID_MAX_CELLS = 1 << 22;
+struct GridInfo {
+  float lo[3];  // finite lower corner of the target
+  float inv_h;  // 1 / cell edge
+  float h;
+  int nx, ny, nz;
+  int ncells;
+};
+void launch_grid_bounds(const float* x, const float* y, const float* z, int n, float* fb, hipStream_t s);
+void launch_grid_info(const float* fb, int n, float ppc, GridInfo* g, hipStream_t s);
+void launch_grid_cid(const float* x, const float* y, const float* z, int n, const GridInfo* g, unsigned* keys,
+                     int* vals, hipStream_t s);
+void launch_grid_gather(const float* x, const float* y, const float* z, const int* perm, int n, float4* t4,
+                        hipStream_t s);
+void launch_grid_starts(const unsigned* sorted_cid, int n, const GridInfo* g, int* cell_start, hipStream_t s);
+void launch_nn_grid(const NnArgs& a, float4* qm4, const float4* t4, const int* cell_start, const GridInfo* g,
+                    const float* ox, const float* oy, const float* oz, const float4* sp_in, float4* sp_out,
+                    nn_key_t* best_m, int slices, int expand, const LoopState* st, hipStream_t s);
+void launch_grid_query_points(const float* qx, const float* qy, const float* qz, const int* qperm, int nq,
+                              const nn_key_t* seed_m, const float* ox, const float* oy, const float* oz, float4* qm4,
+                              float4* sp, hipStream_t s);
 constexpr int NN_SEED_STRIDE = 16;  // decimation of the target for the seeding pre-pass
 void launch_pair_distance(const float* a, const float* b, float* out, int n, hipStream_t s);
 

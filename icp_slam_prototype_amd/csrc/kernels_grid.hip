@@ -1,0 +1,438 @@
+// kernels_grid.hip -- K1d: exact NN through a uniform grid over the target (ICPK_NN_GRID).
+//
+// SURVEY.md 8(f) rank 2 again (the reference's own plan is a voxel look-up, icp.cpp:347-486,
+// map.hpp:9-17), this time with the voxels as the index itself: targets are binned into
+// cubic cells of edge h, sorted by linear cell id (x fastest), and `cell_start` gives the
+// first sorted position of every cell, so the targets of any run of x-adjacent cells are one
+// contiguous range.  A query with a seed match at distance r only has to look at the cells
+// that meet the cube [q - r, q + r]: (cells in y) x (cells in z) contiguous ranges, a few
+// dozen to a few hundred targets instead of all Nt -- and still returns the brute-force
+// result bit for bit: every candidate goes through the same fp32 filter + float64 exact
+// re-evaluation + lexicographic (distance, index) merge as the other kernels, and the cell
+// cube is a superset of every target that could tie or beat the seed (see cube_cells).
+//
+// Set-up (once per target cloud): finite bounds, cell size from the point density, cell ids,
+// rocPRIM radix sort, AoS gather (x, y, z, original index in one 16-byte load), cell starts.
+#include "icpk_internal.h"
+#include "nn_device.h"
+
+namespace icpk {
+
+// ---- set-up ---------------------------------------------------------------------------
+// bounds over the FINITE coordinates only (a non-finite target can never be selected: its
+// distance is inf/NaN, and the seed of such a query is element 0, the lowest index)
+__global__ __launch_bounds__(1024) void grid_bounds_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                           const float* __restrict__ z, int n,
+                                                           float* __restrict__ fb) {
+  __shared__ float red[6][16];
+  const float* p[3] = {x, y, z};
+  float lo[3], hi[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    lo[c] = __builtin_inff();
+    hi[c] = -__builtin_inff();
+    for (int i = threadIdx.x; i < n; i += 1024) {
+      const float v = p[c][i];
+      if (v - v == 0.f) {
+        lo[c] = __builtin_fminf(lo[c], v);
+        hi[c] = __builtin_fmaxf(hi[c], v);
+      }
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+      lo[c] = __builtin_fminf(lo[c], __shfl_xor(lo[c], m, 64));
+      hi[c] = __builtin_fmaxf(hi[c], __shfl_xor(hi[c], m, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+      red[c][threadIdx.x >> 6] = lo[c];
+      red[3 + c][threadIdx.x >> 6] = hi[c];
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    float v = red[threadIdx.x][0];
+    for (int k = 1; k < 16; ++k)
+      v = threadIdx.x < 3 ? __builtin_fminf(v, red[threadIdx.x][k]) : __builtin_fmaxf(v, red[threadIdx.x][k]);
+    fb[threadIdx.x] = v;
+  }
+}
+
+// cell edge: about `ppc` targets per occupied cell if the cloud is a surface whose area is
+// of the order of the bounding box's faces (a depth image is); never more than
+// GRID_MAX_CELLS cells.  Only efficiency depends on the choice.
+__global__ void grid_info_kernel(const float* __restrict__ fb, int n, float ppc, GridInfo* __restrict__ g) {
+  float lo[3], ext[3];
+  float emax = 0.f;
+  for (int c = 0; c < 3; ++c) {
+    const bool ok = fb[c] <= fb[3 + c];  // false if the cloud has no finite point
+    lo[c] = ok ? fb[c] : 0.f;
+    ext[c] = ok ? fb[3 + c] - fb[c] : 0.f;
+    if (!(ext[c] >= 0.f) || !(ext[c] <= 3.0e38f)) ext[c] = 0.f;
+    emax = __builtin_fmaxf(emax, ext[c]);
+  }
+  const float area = ext[0] * ext[1] + ext[1] * ext[2] + ext[2] * ext[0];
+  float h = __builtin_sqrtf(ppc * area / (float)(n > 0 ? n : 1));
+  if (!(h > 0.f) || !(h <= 3.0e38f)) h = emax > 0.f ? emax / 64.f : 1.f;  // a line or a single point
+  h = __builtin_fmaxf(h, emax / 1023.f);  // <= 1024 cells per axis
+  h = __builtin_fmaxf(h, 1e-30f);
+  int nx, ny, nz;
+  for (;;) {
+    nx = (int)(ext[0] / h) + 1;
+    ny = (int)(ext[1] / h) + 1;
+    nz = (int)(ext[2] / h) + 1;
+    if ((long long)nx * ny * nz <= GRID_MAX_CELLS) break;
+    h *= 1.26f;
+  }
+  g->lo[0] = lo[0];
+  g->lo[1] = lo[1];
+  g->lo[2] = lo[2];
+  g->h = h;
+  g->inv_h = 1.0f / h;
+  g->nx = nx;
+  g->ny = ny;
+  g->nz = nz;
+  g->ncells = nx * ny * nz;
+}
+
+// The ONE mapping coordinate -> cell index along an axis, used for targets and for the
+// corners of a query's cube alike.  Every step is monotone non-decreasing in v (float
+// subtraction, multiplication by a positive constant, clamp, truncation of a non-negative
+// value), so a <= t <= b implies cell(a) <= cell(t) <= cell(b).  NaN maps to cell 0.
+__device__ __forceinline__ int grid_cell(float v, float lo, float inv_h, int n) {
+  float f = (v - lo) * inv_h;
+  f = __builtin_fminf(__builtin_fmaxf(f, 0.f), (float)(n - 1));
+  return (int)f;
+}
+
+__global__ void grid_cid_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z,
+                                int n, const GridInfo* __restrict__ gi, unsigned* __restrict__ keys,
+                                int* __restrict__ vals) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const GridInfo g = *gi;
+  const int cx = grid_cell(x[i], g.lo[0], g.inv_h, g.nx);
+  const int cy = grid_cell(y[i], g.lo[1], g.inv_h, g.ny);
+  const int cz = grid_cell(z[i], g.lo[2], g.inv_h, g.nz);
+  keys[i] = (unsigned)((cz * g.ny + cy) * g.nx + cx);
+  vals[i] = i;
+}
+
+__global__ void grid_gather_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                   const float* __restrict__ z, const int* __restrict__ perm, int n,
+                                   float4* __restrict__ t4) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const int j = perm[p];
+  t4[p] = make_float4(x[j], y[j], z[j], __int_as_float(j));
+}
+
+// cell_start[c] = first sorted position whose cell id is >= c, for c = 0 .. ncells
+__global__ void grid_starts_kernel(const unsigned* __restrict__ sorted_cid, int n, const GridInfo* __restrict__ gi,
+                                   int* __restrict__ cell_start) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c > gi->ncells) return;
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (sorted_cid[mid] < (unsigned)c) lo = mid + 1; else hi = mid;
+  }
+  cell_start[c] = lo;
+}
+
+void launch_grid_bounds(const float* x, const float* y, const float* z, int n, float* fb, hipStream_t s) {
+  hipLaunchKernelGGL(grid_bounds_kernel, dim3(1), dim3(1024), 0, s, x, y, z, n, fb);
+}
+void launch_grid_info(const float* fb, int n, float ppc, GridInfo* g, hipStream_t s) {
+  hipLaunchKernelGGL(grid_info_kernel, dim3(1), dim3(1), 0, s, fb, n, ppc, g);
+}
+void launch_grid_cid(const float* x, const float* y, const float* z, int n, const GridInfo* g, unsigned* keys,
+                     int* vals, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(grid_cid_kernel, dim3((n + 255) / 256), dim3(256), 0, s, x, y, z, n, g, keys, vals);
+}
+void launch_grid_gather(const float* x, const float* y, const float* z, const int* perm, int n, float4* t4,
+                        hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(grid_gather_kernel, dim3((n + 255) / 256), dim3(256), 0, s, x, y, z, perm, n, t4);
+}
+void launch_grid_starts(const unsigned* sorted_cid, int n, const GridInfo* g, int* cell_start, hipStream_t s) {
+  hipLaunchKernelGGL(grid_starts_kernel, dim3((GRID_MAX_CELLS + 1 + 255) / 256), dim3(256), 0, s, sorted_cid, n, g,
+                     cell_start);
+}
+
+// ---- the sweep --------------------------------------------------------------------------
+// Cells met by the cube [q - rr, q + rr], rr slightly above the current best distance r.
+// A target that could tie or beat r has |q_c - t_c| <= r on every axis (its float distance
+// is >= |fl(q_c - t_c)| (1 - 2^-22)); rr = r (1 + 2^-19) + |q_c| 2^-21 + 2^-100 also
+// absorbs the rounding of q_c -/+ rr, so fl(q_c - rr) <= t_c <= fl(q_c + rr) and, grid_cell
+// being monotone, the target's cell lies in [c0, c1].
+__device__ __forceinline__ void cube_cells(float q, float r, float lo, float inv_h, int n, int& c0, int& c1) {
+  const float rr = __builtin_fmaf(r, 1.0f + 0x1p-19f, __builtin_fmaf(__builtin_fabsf(q), 0x1p-21f, 0x1p-100f));
+  c0 = grid_cell(q - rr, lo, inv_h, n);
+  c1 = grid_cell(q + rr, lo, inv_h, n);
+}
+
+// S lanes per query (rows of the cube dealt round-robin); the rest of the interface is the
+// pruned kernel's: queries in Morton order (neighbouring lanes read neighbouring cells),
+// seeds / results in that order too, K3 fused in device-loop mode.
+// Diagnostic build only (tools/stamp_grid.py, -DICPK_GRID_STAMPS): per-wave wall_clock64
+// (100 MHz) stamps of the phases and work counters.
+#ifdef ICPK_GRID_STAMPS
+__device__ unsigned long long grid_dbg[8 * 16384];
+#define GRID_STAMP(k)                                                                         \
+  do {                                                                                        \
+    if ((threadIdx.x & 63) == 0 && wave_id < 16384) grid_dbg[wave_id * 8 + (k)] = wall_clock64(); \
+  } while (0)
+#ifdef ICPK_GRID_COUNTS
+#define GRID_COUNT(k, v)                                                                      \
+  do {                                                                                        \
+    if (wave_id < 16384) atomicAdd(&grid_dbg[wave_id * 8 + (k)], (unsigned long long)(v));    \
+  } while (0)
+#else
+#define GRID_COUNT(k, v)
+#endif
+extern "C" int icpk_debug_read_grid_stamps(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(grid_dbg), sizeof(grid_dbg));
+}
+extern "C" int icpk_debug_clear_grid_stamps() {
+  static unsigned long long zero[8 * 16384];
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(grid_dbg), zero, sizeof(zero));
+}
+#else
+#define GRID_STAMP(k)
+#define GRID_COUNT(k, v)
+#endif
+
+#ifndef ICPK_GRID_BLOCK
+#define ICPK_GRID_BLOCK 64
+#endif
+template <int S, bool EXPAND>
+__global__ __launch_bounds__(ICPK_GRID_BLOCK) void nn_grid_kernel(
+    float* __restrict__ qxp, float* __restrict__ qyp, float* __restrict__ qzp, int nq, float4* __restrict__ qm4,
+    const float4* __restrict__ t4, const int* __restrict__ cell_start, const GridInfo* __restrict__ gi,
+    const float* __restrict__ oxp, const float* __restrict__ oyp, const float* __restrict__ ozp,
+    const float4* __restrict__ sp_in, float4* __restrict__ sp_out, nn_key_t* __restrict__ best,
+    nn_key_t* __restrict__ best_m, const LoopState* __restrict__ st) {
+  // qm4: the queries in Morton order, (x, y, z, original index) -- one coalesced 16-byte load
+  // instead of the qperm -> coordinates chain; kept in step with the caller's planes here.
+  // sp_in / sp_out: the seed of every query as a point (x, y, z, target index), again in query
+  // Morton order: the match of the previous sweep, written by that sweep.
+  bool apply_rt = false, stop_after = false;
+  if (st) {
+    if (st->done) return;
+    stop_after = st->stop_after_transform != 0;
+    apply_rt = st->iterations > 0 || stop_after;
+  }
+  constexpr int NQ = 64 / S;
+  const int lane = threadIdx.x & 63;
+  const int slice = lane / NQ;
+  const int wave_id = blockIdx.x * (ICPK_GRID_BLOCK / 64) + (threadIdx.x >> 6);
+  const int ip = wave_id * NQ + (lane % NQ);
+  GRID_STAMP(0);
+  const bool live = ip < nq;
+  const float4 q4 = live ? qm4[ip] : make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4 s4 = live ? sp_in[ip] : make_float4(0.f, 0.f, 0.f, 0.f);
+  const int i = __float_as_int(q4.w);
+  float qx = q4.x, qy = q4.y, qz = q4.z;
+  if (apply_rt) {  // pointcloud.cpp:321-359: p <- fl32(fl32(R p) + t)
+    const Rt rt = st->rt;
+    const double px = qx, py = qy, pz = qz;
+    qx = (float)__builtin_fma((double)rt.R[2], pz, __builtin_fma((double)rt.R[1], py, (double)rt.R[0] * px)) + rt.t[0];
+    qy = (float)__builtin_fma((double)rt.R[5], pz, __builtin_fma((double)rt.R[4], py, (double)rt.R[3] * px)) + rt.t[1];
+    qz = (float)__builtin_fma((double)rt.R[8], pz, __builtin_fma((double)rt.R[7], py, (double)rt.R[6] * px)) + rt.t[2];
+    if (live && slice == 0) {
+      qm4[ip] = make_float4(qx, qy, qz, q4.w);
+      qxp[i] = qx;
+      qyp[i] = qy;
+      qzp[i] = qz;
+    }
+    if (stop_after) return;  // < min_pairs fallback: the motion is applied, no further search
+  }
+  int bj = __float_as_int(s4.w);
+  float bx = s4.x, by = s4.y, bz = s4.z;
+  float bd = pair_dist(qx, qy, qz, bx, by, bz);
+  if (!(bd <= 3.402823466e38f)) {  // inf/NaN: the reference's literal seed, element 0
+    bj = 0;
+    bx = oxp[0];
+    by = oyp[0];
+    bz = ozp[0];
+    bd = pair_dist(qx, qy, qz, bx, by, bz);
+  }
+  float T = filt_threshold(bd);
+  GRID_STAMP(1);
+
+  // a NaN best distance can never be replaced (d < NaN and d == NaN are false): no scan
+  const bool scan = live && bd == bd;
+  const GridInfo g = *gi;
+  // The S lanes of a query share the rows of a cell box: L lanes per row (L = largest power of
+  // two with nrows * L <= S, at least 1), S / L rows at a time.  Every lane fetches the range
+  // of its own row and then up to GB of its targets in one go, so a wave needs one round trip
+  // for the ranges and one for the candidates instead of two per row.
+  constexpr int GB = 8;
+  auto scan_cells = [&](int x0, int x1, int y0, int y1, int z0, int z1) {
+    const int nyr = y1 - y0 + 1;
+#ifdef ICPK_GRID_NOSCAN
+    const int nrows = 0;
+#else
+    const int nrows = scan ? nyr * (z1 - z0 + 1) : 0;
+#endif
+    int L = S;
+    while (L > 1 && nrows * L > S) L >>= 1;
+    const int rstep = S / L;
+    const int sub = slice & (L - 1);
+    if (slice == 0) GRID_COUNT(5, nrows);
+    for (int row = slice / L; row < nrows; row += rstep) {
+      const int rz = row / nyr;
+      const int ry = row - rz * nyr;
+      const int base = ((z0 + rz) * g.ny + (y0 + ry)) * g.nx;
+      const int s0 = cell_start[base + x0];
+      const int e = cell_start[base + x1 + 1];
+      if (sub == 0) GRID_COUNT(6, e - s0);
+#if defined(ICPK_GRID_STAMPS) && !defined(ICPK_GRID_COUNTS)
+      if (e - s0 > -1 && row == 0 && grid_dbg[wave_id * 8 + 5] == 0) GRID_STAMP(5);  // ranges have arrived
+#endif
+      for (int p = s0 + sub; p < e; p += GB * L) {
+        float4 v[GB];
+#pragma unroll
+        for (int k = 0; k < GB; ++k) v[k] = t4[p + k * L < e ? p + k * L : p];
+#if defined(ICPK_GRID_STAMPS) && !defined(ICPK_GRID_COUNTS)
+        if (v[GB - 1].x == v[GB - 1].x && row == 0 && grid_dbg[wave_id * 8 + 6] == 0) GRID_STAMP(6);  // first batch has arrived
+#endif
+#pragma unroll
+        for (int k = 0; k < GB; ++k) {
+          const float dx = qx - v[k].x, dy = qy - v[k].y, dz = qz - v[k].z;
+          const float e2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+          if (e2 <= T && p + k * L < e) {
+            const float d = pair_dist(qx, qy, qz, v[k].x, v[k].y, v[k].z);
+            const int jj = __float_as_int(v[k].w);
+            const bool up = (d < bd) | ((d == bd) & (jj < bj));
+            bd = up ? d : bd;
+            bj = up ? jj : bj;
+            bx = up ? v[k].x : bx;
+            by = up ? v[k].y : by;
+            bz = up ? v[k].z : bz;
+            T = up ? filt_threshold(d) : T;
+          }
+        }
+      }
+    }
+  };
+  // Expanding search: pass k looks at the cells within R = 1, 2, 4, ... of the query's own
+  // cell (clipped to the cube of the current best distance), the S lanes share what they
+  // found, and the search ends as soon as the cube of the shared best distance lies inside the
+  // box just scanned -- then every target that could tie or beat it has been examined.  With a
+  // good seed that is the first pass; a loose or far seed costs work proportional to the true
+  // NN distance, not to the seed's.  EXPAND = false (seeds are the previous sweep's matches):
+  // one pass over the whole cube of the seed distance -- fewer round trips than two passes,
+  // and a leaner kernel.
+  auto share = [&]() {  // the S lanes of a query agree on the best (distance, index, point) so far
+    if (S > 1) {
+      nn_key_t k2 = ((nn_key_t)__float_as_uint(bd) << 32) | (nn_key_t)(unsigned)bj;
+#pragma unroll
+      for (int m = NQ; m < 64; m <<= 1) {  // butterfly: the winner's point travels with its key
+        const nn_key_t o = __shfl_xor(k2, m, 64);
+        const float ox_ = __shfl_xor(bx, m, 64), oy_ = __shfl_xor(by, m, 64), oz_ = __shfl_xor(bz, m, 64);
+        const bool take = o < k2;
+        k2 = take ? o : k2;
+        bx = take ? ox_ : bx;
+        by = take ? oy_ : by;
+        bz = take ? oz_ : bz;
+      }
+      if (scan) {  // (a NaN distance is not ordered by its bits; such lanes never scan)
+        bd = __uint_as_float((unsigned)(k2 >> 32));
+        bj = (int)(unsigned)(k2 & 0xffffffffu);
+        T = filt_threshold(bd);
+      }
+    }
+  };
+  GRID_STAMP(2);
+  if constexpr (!EXPAND) {
+    int x0, x1, y0, y1, z0, z1;
+    cube_cells(qx, bd, g.lo[0], g.inv_h, g.nx, x0, x1);
+    cube_cells(qy, bd, g.lo[1], g.inv_h, g.ny, y0, y1);
+    cube_cells(qz, bd, g.lo[2], g.inv_h, g.nz, z0, z1);
+    scan_cells(x0, x1, y0, y1, z0, z1);
+    share();
+  } else {
+    const int cx = grid_cell(qx, g.lo[0], g.inv_h, g.nx);
+    const int cy = grid_cell(qy, g.lo[1], g.inv_h, g.ny);
+    const int cz = grid_cell(qz, g.lo[2], g.inv_h, g.nz);
+    bool active = scan;
+    for (int R = 1; __builtin_amdgcn_ballot_w64(active) != 0; R = R < (1 << 20) ? 2 * R : R) {
+      int X0, X1, Y0, Y1, Z0, Z1;
+      cube_cells(qx, bd, g.lo[0], g.inv_h, g.nx, X0, X1);
+      cube_cells(qy, bd, g.lo[1], g.inv_h, g.ny, Y0, Y1);
+      cube_cells(qz, bd, g.lo[2], g.inv_h, g.nz, Z0, Z1);
+      const int x0 = max(X0, cx - R), x1 = min(X1, cx + R);
+      const int y0 = max(Y0, cy - R), y1 = min(Y1, cy + R);
+      const int z0 = max(Z0, cz - R), z1 = min(Z1, cz + R);
+      if (active) scan_cells(x0, x1, y0, y1, z0, z1);
+      share();
+      cube_cells(qx, bd, g.lo[0], g.inv_h, g.nx, X0, X1);
+      cube_cells(qy, bd, g.lo[1], g.inv_h, g.ny, Y0, Y1);
+      cube_cells(qz, bd, g.lo[2], g.inv_h, g.nz, Z0, Z1);
+      active = active && !(X0 >= x0 && X1 <= x1 && Y0 >= y0 && Y1 <= y1 && Z0 >= z0 && Z1 <= z1);
+    }
+  }
+
+  GRID_STAMP(3);
+  // (the S lanes of a query already agree: the last pass ended with a merge)
+  const nn_key_t key = ((nn_key_t)__float_as_uint(bd) << 32) | (nn_key_t)(unsigned)bj;
+  if (live && slice == 0) {
+    best[i] = key;
+    best_m[ip] = key;
+    sp_out[ip] = make_float4(bx, by, bz, __int_as_float((int)(unsigned)(key & 0xffffffffu)));
+  }
+  GRID_STAMP(4);
+}
+
+void launch_nn_grid(const NnArgs& a, float4* qm4, const float4* t4, const int* cell_start, const GridInfo* g,
+                    const float* ox, const float* oy, const float* oz, const float4* sp_in, float4* sp_out,
+                    nn_key_t* best_m, int slices, int expand, const LoopState* st, hipStream_t s) {
+#define ICPK_LAUNCH2(SL, EX)                                                                             \
+  hipLaunchKernelGGL((nn_grid_kernel<SL, EX>),                                                           \
+                     dim3((a.nq + (ICPK_GRID_BLOCK / SL) - 1) / (ICPK_GRID_BLOCK / SL)), dim3(ICPK_GRID_BLOCK), 0, s, \
+                     const_cast<float*>(a.qx), const_cast<float*>(a.qy), const_cast<float*>(a.qz), a.nq, \
+                     qm4, t4, cell_start, g, ox, oy, oz, sp_in, sp_out, a.best, best_m, st)
+#define ICPK_LAUNCH(SL)    \
+  do {                     \
+    if (expand) {          \
+      ICPK_LAUNCH2(SL, true);  \
+    } else {               \
+      ICPK_LAUNCH2(SL, false); \
+    }                      \
+  } while (0)
+  switch (slices) {
+    case 1: ICPK_LAUNCH(1); break;
+    case 2: ICPK_LAUNCH(2); break;
+    case 8: ICPK_LAUNCH(8); break;
+    default: ICPK_LAUNCH(4); break;
+  }
+#undef ICPK_LAUNCH
+#undef ICPK_LAUNCH2
+}
+
+// queries / seeds of a sweep that does not continue a chain of grid sweeps: Morton-ordered
+// copies from the caller's planes and from the seed keys
+__global__ void grid_query_points_kernel(const float* __restrict__ qx, const float* __restrict__ qy,
+                                         const float* __restrict__ qz, const int* __restrict__ qperm, int nq,
+                                         const nn_key_t* __restrict__ seed_m, const float* __restrict__ ox,
+                                         const float* __restrict__ oy, const float* __restrict__ oz,
+                                         float4* __restrict__ qm4, float4* __restrict__ sp) {
+  const int ip = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ip >= nq) return;
+  const int i = qperm[ip];
+  qm4[ip] = make_float4(qx[i], qy[i], qz[i], __int_as_float(i));
+  const int js = (int)(unsigned)(seed_m[ip] & 0xffffffffu);
+  sp[ip] = make_float4(ox[js], oy[js], oz[js], __int_as_float(js));
+}
+
+void launch_grid_query_points(const float* qx, const float* qy, const float* qz, const int* qperm, int nq,
+                              const nn_key_t* seed_m, const float* ox, const float* oy, const float* oz, float4* qm4,
+                              float4* sp, hipStream_t s) {
+  if (nq <= 0) return;
+  hipLaunchKernelGGL(grid_query_points_kernel, dim3((nq + 255) / 256), dim3(256), 0, s, qx, qy, qz, qperm, nq, seed_m,
+                     ox, oy, oz, qm4, sp);
+}
+
+}  // namespace icpk

@@ -14,6 +14,21 @@
 
 namespace icpk {
 
+// Diagnostic build only (tools/stamp_step.py, -DICPK_STEP_STAMPS): wall_clock64 (100 MHz)
+// stamps of the phases of loop_step_kernel, one row per iteration.
+#ifdef ICPK_STEP_STAMPS
+__device__ unsigned long long step_dbg[8 * 64];
+#define STEP_STAMP(i, k)                                                        \
+  do {                                                                          \
+    if (threadIdx.x == 0 && (i) < 64) step_dbg[(i) * 8 + (k)] = wall_clock64(); \
+  } while (0)
+extern "C" int icpk_debug_read_step_stamps(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(step_dbg), sizeof(step_dbg));
+}
+#else
+#define STEP_STAMP(i, k)
+#endif
+
 // canonical stage 2: 256 slots (slot b = sums of block b, +0.0 beyond nblocks), one slot
 // per lane; wave butterfly, ((w0+w1)+w2)+w3.  Result in sums[] of thread 0.
 template <int NS>
@@ -87,9 +102,11 @@ __global__ __launch_bounds__(256) void loop_step_kernel(const double* __restrict
   const int done = st->done, stop_after = st->stop_after_transform, i = st->iterations;
   const int max_iterations = st->max_iterations, min_pairs = st->min_pairs, fixed = st->fixed_iterations;
   const float threshold = st->threshold;
+  STEP_STAMP(i, 0);
   double sums[NS];
   long long npairs = 0;
   tree_stage2<NS>(partial, pcount, nblocks, sums, npairs);
+  STEP_STAMP(i, 1);
   if (done) return;
   if (stop_after) {  // the fallback motion has been applied by the previous transform
     if (threadIdx.x == 0) st->done = 1;
@@ -124,6 +141,7 @@ __global__ __launch_bounds__(256) void loop_step_kernel(const double* __restrict
   st->trace_pairs[i] = (int)npairs;
   st->trace_mse[i] = mse;
   float Rrec[9], trec[3];
+  STEP_STAMP(i, 2);
   if (NS == NP2L) {
     double Rd[9], td[3];
     if (!solve_p2l(sums, Rd, td)) {
@@ -170,9 +188,11 @@ __global__ __launch_bounds__(256) void loop_step_kernel(const double* __restrict
     for (int k = 0; k < 3; ++k) st->rt.t[k] = trec[k];
     compose_rt(Rrec, trec, st->Tk);
   }
+  STEP_STAMP(i, 3);
   for (int k = 0; k < 9; ++k) st->trace_R[9 * i + k] = Rrec[k];
   for (int k = 0; k < 3; ++k) st->trace_t[3 * i + k] = trec[k];
   st->iterations = i + 1;  // icp.cpp:257 (the sweep that follows is already enqueued)
+  STEP_STAMP(i, 4);
 }
 
 void launch_loop_step(const double* partial, const int* pcount, int nblocks, int nsum, LoopState* st, int stats_only,

@@ -329,7 +329,7 @@ def test_backproject_bit_exact(ctx, oracle):
 
 
 # ------------------------------------------------- filtered NN (ICPK_NN_FILTERED) --
-def _check_nn_filtered(ctx, oracle, src, tgt, moves=2, modes=(binding.NN_FILTERED, binding.NN_PRUNED)):
+def _check_nn_filtered(ctx, oracle, src, tgt, moves=2, modes=(binding.NN_FILTERED, binding.NN_PRUNED, binding.NN_GRID)):
     """First sweep (coarse-seeded) and re-sweeps after moving the source (seeded by
     the previous matches) must equal the oracle bit for bit, with and without
     bounding-box pruning."""
@@ -366,7 +366,7 @@ def test_nn_filtered_ties_collisions_duplicates(ctx, oracle):
     _check_nn_filtered(ctx, oracle, p["source"], p["target"])
     tgt2 = np.concatenate([p["target"], p["target"]], axis=1)  # exact twins 4800 later
     _check_nn_filtered(ctx, oracle, p["source"], tgt2)
-    for mode in (binding.NN_FILTERED, binding.NN_PRUNED):
+    for mode in (binding.NN_FILTERED, binding.NN_PRUNED, binding.NN_GRID):
         ctx.set_target(tgt2)
         ctx.set_source(p["source"])
         idx, _ = ctx.nn(mode)
@@ -378,7 +378,7 @@ def test_nn_filtered_ties_collisions_duplicates(ctx, oracle):
     tgt = np.stack([np.ones_like(ys), ys, np.zeros_like(ys)]).astype(np.float32)
     far = np.full((3, 3000), 50, np.float32)
     for t in (tgt, np.concatenate([tgt[:, :63], far, tgt[:, 63:]], axis=1)):
-        for mode in (binding.NN_FILTERED, binding.NN_PRUNED):
+        for mode in (binding.NN_FILTERED, binding.NN_PRUNED, binding.NN_GRID):
             ctx.set_target(t)
             ctx.set_source(q)
             idx, dist = ctx.nn(mode)
@@ -414,11 +414,13 @@ def test_nn_filtered_kinect_quarter_frame_and_exact_agree(ctx, oracle):
     a = ctx.nn(binding.NN_EXACT)
     b = ctx.nn(binding.NN_FILTERED)  # seeded by the exact sweep's matches
     c = ctx.nn(binding.NN_PRUNED)
+    g = ctx.nn(binding.NN_GRID)
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
     assert np.array_equal(a[0], c[0]) and np.array_equal(a[1], c[1])
+    assert np.array_equal(a[0], g[0]) and np.array_equal(a[1], g[1])
 
 
-@pytest.mark.parametrize("mode", [binding.NN_FILTERED, binding.NN_PRUNED])
+@pytest.mark.parametrize("mode", [binding.NN_FILTERED, binding.NN_PRUNED, binding.NN_GRID])
 @pytest.mark.parametrize("solve", [binding.SOLVE_REFERENCE, binding.SOLVE_KABSCH])
 def test_align_filtered_matches_oracle(ctx, oracle, solve, mode):
     p = synth.kinect_pair(rows=240, cols=320, seed=3)
@@ -450,6 +452,9 @@ def test_full_size_kinect_pair_properties(ctx):
     ctx.reset_source()
     i_p, d_p = ctx.nn(binding.NN_PRUNED)
     assert np.array_equal(ie, i_p) and np.array_equal(de.view(np.uint32), d_p.view(np.uint32))
+    ctx.reset_source()
+    i_g, d_g = ctx.nn(binding.NN_GRID)
+    assert np.array_equal(ie, i_g) and np.array_equal(de.view(np.uint32), d_g.view(np.uint32))
     assert np.array_equal(ctx.pair_distance(src, tgt[:, ie]).view(np.uint32), de.view(np.uint32))
     rng = np.random.default_rng(0)
     for q in rng.integers(0, src.shape[1], 40):
@@ -460,6 +465,8 @@ def test_full_size_kinect_pair_properties(ctx):
     assert np.array_equal(T1, T2) and st1.final_pairs == st2.final_pairs and st1.final_mse == st2.final_mse
     T3, st3, _ = ctx.align(max_iterations=3, fixed_iterations=1, nn_mode=binding.NN_PRUNED)
     assert np.array_equal(T1, T3) and st1.final_pairs == st3.final_pairs and st1.final_mse == st3.final_mse
+    T4, st4, _ = ctx.align(max_iterations=3, fixed_iterations=1, nn_mode=binding.NN_GRID)
+    assert np.array_equal(T1, T4) and st1.final_pairs == st4.final_pairs and st1.final_mse == st4.final_mse
 
 
 def test_transform_target_commit_and_trace(ctx, oracle):
@@ -539,7 +546,7 @@ def test_align_point_to_plane_matches_oracle(ctx, oracle):
     tgt = pts + np.float32(5)
     ctx.backproject_with_normals(p["depth_tgt"], 0, fx=fx, cx=cx, offset=[5, 5, 5])
     ctx.set_source(p["source"])
-    for mode in (binding.NN_EXACT, binding.NN_PRUNED):
+    for mode in (binding.NN_EXACT, binding.NN_PRUNED, binding.NN_GRID):
         T, st, rc = ctx.align(solve=binding.SOLVE_POINT_TO_PLANE, max_iterations=10, fixed_iterations=1,
                               max_nn_dist=0.3, nn_mode=mode)
         o = oracle.align(p["source"], tgt, max_iterations=10, solve=2, sum_order=1, fixed_iterations=True, threads=8,
@@ -575,13 +582,16 @@ def test_config3_full_size_properties(ctx):
     T2, st2, _ = ctx.align(solve=binding.SOLVE_POINT_TO_PLANE, max_iterations=3, fixed_iterations=1, max_nn_dist=0.3,
                            nn_mode=binding.NN_PRUNED)
     assert np.array_equal(T1, T2) and st1.final_pairs == st2.final_pairs
+    Tg, stg, _ = ctx.align(solve=binding.SOLVE_POINT_TO_PLANE, max_iterations=3, fixed_iterations=1, max_nn_dist=0.3,
+                           nn_mode=binding.NN_GRID)
+    assert np.array_equal(T1, Tg) and st1.final_pairs == stg.final_pairs
     T3, st3, _ = ctx.align(solve=binding.SOLVE_POINT_TO_PLANE, max_iterations=15, fixed_iterations=1, max_nn_dist=0.3)
     assert np.linalg.norm(T3[:3, :3].astype(np.float64) - p["R_true"]) < 2e-3
 
 
 # ------------------------------------------------ device-side loop vs host loop --
 @pytest.mark.parametrize("solve", [binding.SOLVE_REFERENCE, binding.SOLVE_KABSCH, binding.SOLVE_POINT_TO_PLANE])
-@pytest.mark.parametrize("mode", [binding.NN_EXACT, binding.NN_FILTERED, binding.NN_PRUNED])
+@pytest.mark.parametrize("mode", [binding.NN_EXACT, binding.NN_FILTERED, binding.NN_PRUNED, binding.NN_GRID])
 def test_device_loop_equals_host_loop(ctx, oracle, solve, mode):
     """params.host_loop = 0 (default: loop test + solve on the device, everything enqueued
     up front) and 1 (host drives each iteration) must give the same bits."""
@@ -652,7 +662,12 @@ def test_config5_unordered_clouds_exact_vs_pruned(ctx):
     ctx.reset_source()
     ip, dp = ctx.nn(binding.NN_PRUNED)
     assert np.array_equal(ie, ip) and np.array_equal(de.view(np.uint32), dp.view(np.uint32))
+    ctx.reset_source()
+    ig, dg = ctx.nn(binding.NN_GRID)
+    assert np.array_equal(ie, ig) and np.array_equal(de.view(np.uint32), dg.view(np.uint32))
+    Tg, stg, _ = ctx.align(max_iterations=3, fixed_iterations=1, solve=binding.SOLVE_KABSCH, nn_mode=binding.NN_GRID)
     T1, st1, _ = ctx.align(max_iterations=3, fixed_iterations=1, solve=binding.SOLVE_KABSCH, nn_mode=binding.NN_PRUNED)
+    assert np.array_equal(T1, Tg) and st1.final_pairs == stg.final_pairs
     T2, st2, _ = ctx.align(max_iterations=3, fixed_iterations=1, solve=binding.SOLVE_KABSCH, nn_mode=binding.NN_FILTERED)
     assert np.array_equal(T1, T2) and st1.final_pairs == st2.final_pairs
     i1, _ = ctx.get_associations()
@@ -708,7 +723,8 @@ def test_fuzz_three_kernels_agree(ctx, seed):
     ctx.set_source(src)
     for sweep in range(3):
         res = []
-        for mode in (binding.NN_EXACT, binding.NN_FILTERED, binding.NN_PRUNED, binding.NN_PRUNED):
+        for mode in (binding.NN_EXACT, binding.NN_FILTERED, binding.NN_PRUNED, binding.NN_PRUNED, binding.NN_GRID,
+                     binding.NN_GRID):
             res.append(ctx.nn(mode))  # the second pruned sweep is seeded by the first one's Morton-ordered matches
         for r in res[1:]:
             assert np.array_equal(res[0][0], r[0]), (kt, ks, nt, nq, sweep)
@@ -732,7 +748,7 @@ def test_non_finite_inputs_do_not_fault(ctx):
     ok = np.ones(3000, bool)
     ok[[5, 700, 2999]] = False
     ie, de = ctx.nn(binding.NN_EXACT)
-    for mode in (binding.NN_FILTERED, binding.NN_PRUNED):
+    for mode in (binding.NN_FILTERED, binding.NN_PRUNED, binding.NN_GRID):
         ctx.reset_source()
         i2, d2 = ctx.nn(mode)
         assert np.array_equal(ie[ok], i2[ok]) and np.array_equal(de[ok], d2[ok])
@@ -751,6 +767,9 @@ def test_config5_full_size_one_sweep(ctx):
     ctx.reset_source()
     ip, dp = ctx.nn(binding.NN_PRUNED)
     assert np.array_equal(ie, ip) and np.array_equal(de.view(np.uint32), dp.view(np.uint32))
+    ctx.reset_source()
+    ig, dg = ctx.nn(binding.NN_GRID)
+    assert np.array_equal(ie, ig) and np.array_equal(de.view(np.uint32), dg.view(np.uint32))
     sums, cnt = ctx.reduce(0.75)
     assert cnt == 1_000_000
 
@@ -798,7 +817,10 @@ def test_lopsided_sizes_exact_vs_pruned(ctx, nq, nt):
     ctx.reset_source()
     ip, dp = ctx.nn(binding.NN_PRUNED)
     ip2, dp2 = ctx.nn(binding.NN_PRUNED)  # seeded re-sweep
-    for i2, d2 in ((i_f, d_f), (ip, dp), (ip2, dp2)):
+    ctx.reset_source()
+    ig, dg = ctx.nn(binding.NN_GRID)
+    ig2, dg2 = ctx.nn(binding.NN_GRID)
+    for i2, d2 in ((i_f, d_f), (ip, dp), (ip2, dp2), (ig, dg), (ig2, dg2)):
         assert np.array_equal(ie, i2) and np.array_equal(de.view(np.uint32), d2.view(np.uint32))
     T1, s1, _ = ctx.align(max_iterations=2, fixed_iterations=1, solve=binding.SOLVE_KABSCH)
     T2, s2, _ = ctx.align(max_iterations=2, fixed_iterations=1, solve=binding.SOLVE_KABSCH, nn_mode=binding.NN_EXACT,

@@ -11,7 +11,8 @@ binding.LIB_PATH = build.build(force=True, extra=flags, out=f"/tmp/icpk_{tag}/li
 p = synth.kinect_pair(480, 640, valid=0.30, seed=2)
 ctx = binding.Context(0)
 ctx.set_target(p["target"]); ctx.set_source(p["source"])
-par = binding.default_params(max_iterations=20, fixed_iterations=1, profile=0)
+mode = int(os.environ.get("ICPK_AB_MODE", binding.NN_PRUNED))
+par = binding.default_params(max_iterations=20, fixed_iterations=1, profile=0, nn_mode=mode)
 for _ in range(3):
     ctx.align(par)
 best = 1e9
@@ -22,4 +23,4 @@ for _ in range(5):
     best = min(best, (time.perf_counter() - t) / 10)
 par.profile = 2
 _, st, _ = ctx.align(par)
-print(f"{tag}: {20 / best:9.1f} iter/s  ({best * 1e3:.3f} ms/align; nn {st.nn_ms_total:.3f} reduce {st.reduce_ms_total:.3f} ms)  T[0,3]={T[0,3]:.6f}")
+print(f"{tag} mode={mode} ppc={os.environ.get('ICPK_GRID_PPC')} gs={os.environ.get('ICPK_GRID_SLICES')}: {20 / best:9.1f} iter/s  ({best * 1e3:.3f} ms/align; nn {st.nn_ms_total:.3f} reduce {st.reduce_ms_total:.3f} ms)  T[0,3]={T[0,3]:.6f}")

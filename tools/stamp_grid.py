@@ -1,0 +1,33 @@
+"""Diagnostic (tools only): phases and work counters of nn_grid_kernel (-DICPK_GRID_STAMPS)."""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from icp_slam_prototype_amd import build, binding, synth
+
+os.makedirs("/tmp/icpk_gs", exist_ok=True)
+binding.LIB_PATH = build.build(force=True, extra=["-DICPK_GRID_STAMPS"], out="/tmp/icpk_gs/libicpk.so")
+p = synth.kinect_pair(480, 640, valid=0.30, seed=2)
+ctx = binding.Context(0)
+ctx.set_target(p["target"]); ctx.set_source(p["source"])
+L = binding.load()
+NW = 16384
+for first in (True, False):
+    ctx.reset_source()
+    if not first:
+        ctx.align(max_iterations=8, fixed_iterations=1, nn_mode=binding.NN_GRID, host_loop=1)
+    L.icpk_debug_clear_grid_stamps()
+    ctx.nn(binding.NN_GRID, fetch=False)
+    buf = np.zeros(8 * NW, np.uint64)
+    L.icpk_debug_read_grid_stamps(buf.ctypes.data_as(C.POINTER(C.c_ulonglong)))
+    b = buf.reshape(NW, 8).astype(np.int64)
+    b = b[b[:, 0] > 0]
+    t0 = b[:, 0].min()
+    print("first sweep" if first else "steady sweep", "waves", len(b), "kernel span us", (b[:, 4].max() - t0) / 100.0)
+    for name, a, c in (("init", 0, 1), ("cube", 1, 2), ("ranges", 2, 5), ("batch1", 5, 6), ("rest", 6, 3),
+                       ("scan", 2, 3), ("write", 3, 4), ("total", 0, 4)):
+        ok = (b[:, a] > 0) & (b[:, c] > 0)
+        v = (b[ok, c] - b[ok, a]) * 10.0
+        print(f"  {name:7s} ns: mean {v.mean():8.0f} p50 {np.median(v):8.0f} p90 {np.quantile(v, 0.9):8.0f} max {v.max():8.0f}")
+    st = (b[:, 0] - t0) * 10.0
+    print(f"  wave start ns: p50 {np.median(st):.0f} p90 {np.quantile(st, 0.9):.0f} max {st.max():.0f}")
+
