@@ -103,7 +103,7 @@ struct icpk_ctx {
   bool grid_chain = false;   // device loop only: the previous sweep was a grid sweep (qm4 / sp_in current)
   int t4_cap = 0;
   bool have_grid = false;  // grid matches tgt
-  float grid_ppc = 8.f;    // aimed-at targets per occupied cell
+  float grid_ppc = 6.f;    // aimed-at targets per occupied cell (measured best on config 2: 6)
   int grid_slices = 0;     // lanes per query (0 = by cloud size)
   std::string err;
   icpk_log_fn log_fn = nullptr;

@@ -203,9 +203,7 @@ extern "C" int icpk_debug_clear_grid_stamps() {
 #define GRID_COUNT(k, v)
 #endif
 
-#ifndef ICPK_GRID_BLOCK
-#define ICPK_GRID_BLOCK 64
-#endif
+#define ICPK_GRID_BLOCK 64  // one wave per workgroup (the row table in LDS relies on it)
 template <int S, bool EXPAND>
 __global__ __launch_bounds__(ICPK_GRID_BLOCK) void nn_grid_kernel(
     float* __restrict__ qxp, float* __restrict__ qyp, float* __restrict__ qzp, int nq, float4* __restrict__ qm4,
@@ -225,9 +223,11 @@ __global__ __launch_bounds__(ICPK_GRID_BLOCK) void nn_grid_kernel(
   }
   constexpr int NQ = 64 / S;
   const int lane = threadIdx.x & 63;
-  const int slice = lane / NQ;
+  // the S lanes of a query are ADJACENT lanes: they read S consecutive targets (one or two
+  // cache lines per query and load instruction instead of one line per lane)
+  const int slice = lane & (S - 1);
   const int wave_id = blockIdx.x * (ICPK_GRID_BLOCK / 64) + (threadIdx.x >> 6);
-  const int ip = wave_id * NQ + (lane % NQ);
+  const int ip = wave_id * NQ + lane / S;
   GRID_STAMP(0);
   const bool live = ip < nq;
   const float4 q4 = live ? qm4[ip] : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -264,11 +264,14 @@ __global__ __launch_bounds__(ICPK_GRID_BLOCK) void nn_grid_kernel(
   // a NaN best distance can never be replaced (d < NaN and d == NaN are false): no scan
   const bool scan = live && bd == bd;
   const GridInfo g = *gi;
-  // The S lanes of a query share the rows of a cell box: L lanes per row (L = largest power of
-  // two with nrows * L <= S, at least 1), S / L rows at a time.  Every lane fetches the range
-  // of its own row and then up to GB of its targets in one go, so a wave needs one round trip
-  // for the ranges and one for the candidates instead of two per row.
+  // The S lanes of a query share the candidates of a cell box evenly.  Rows are taken S at a
+  // time: lane k fetches the range of row k, a prefix sum over the S lanes numbers the
+  // candidates of the chunk 0 .. C-1, and lane k evaluates candidates k, k + S, k + 2S, ...,
+  // GB of them per round trip, whatever row they are in.  So a chunk costs one trip for its
+  // ranges and ceil(C / (S GB)) trips for its candidates, however unevenly the rows are filled.
   constexpr int GB = 8;
+  __shared__ int2 rowtab[64];  // per query and row of the chunk: (inclusive prefix, start - exclusive prefix)
+  int2* const tab = &rowtab[lane & ~(S - 1)];
   auto scan_cells = [&](int x0, int x1, int y0, int y1, int z0, int z1) {
     const int nyr = y1 - y0 + 1;
 #ifdef ICPK_GRID_NOSCAN
@@ -276,33 +279,54 @@ __global__ __launch_bounds__(ICPK_GRID_BLOCK) void nn_grid_kernel(
 #else
     const int nrows = scan ? nyr * (z1 - z0 + 1) : 0;
 #endif
-    int L = S;
-    while (L > 1 && nrows * L > S) L >>= 1;
-    const int rstep = S / L;
-    const int sub = slice & (L - 1);
     if (slice == 0) GRID_COUNT(5, nrows);
-    for (int row = slice / L; row < nrows; row += rstep) {
-      const int rz = row / nyr;
-      const int ry = row - rz * nyr;
-      const int base = ((z0 + rz) * g.ny + (y0 + ry)) * g.nx;
-      const int s0 = cell_start[base + x0];
-      const int e = cell_start[base + x1 + 1];
-      if (sub == 0) GRID_COUNT(6, e - s0);
+    for (int r0 = 0; r0 < nrows; r0 += S) {
+      const int row = r0 + slice;
+      int s0 = 0, len = 0;
+      if (row < nrows) {
+        const int rz = row / nyr;
+        const int ry = row - rz * nyr;
+        const int base = ((z0 + rz) * g.ny + (y0 + ry)) * g.nx;
+        s0 = cell_start[base + x0];
+        len = cell_start[base + x1 + 1] - s0;
+      }
+      GRID_COUNT(6, len);
+      int P = len;
+#pragma unroll
+      for (int d = 1; d < S; d <<= 1) {
+        const int o = __shfl_up(P, d, 64);
+        if (slice >= d) P += o;
+      }
+      const int C = __shfl(P, lane | (S - 1), 64);
+      __builtin_amdgcn_wave_barrier();  // the previous chunk's table has been read
+      tab[slice] = make_int2(P, s0 - (P - len));
+      __builtin_amdgcn_wave_barrier();  // (one wave per workgroup: LDS operations complete in order)
 #if defined(ICPK_GRID_STAMPS) && !defined(ICPK_GRID_COUNTS)
-      if (e - s0 > -1 && row == 0 && grid_dbg[wave_id * 8 + 5] == 0) GRID_STAMP(5);  // ranges have arrived
+      if (C > -1 && r0 == 0 && grid_dbg[wave_id * 8 + 5] == 0) GRID_STAMP(5);  // ranges have arrived
 #endif
-      for (int p = s0 + sub; p < e; p += GB * L) {
+      for (int v0 = slice; v0 < C; v0 += S * GB) {
+        int pk[GB];
+        int2 rt = tab[0];
+#pragma unroll
+        for (int k = 0; k < GB; ++k) pk[k] = rt.y + v0 + k * S;
+#pragma unroll
+        for (int t = 1; t < S; ++t) {
+          const int pprev = rt.x;
+          rt = tab[t];
+#pragma unroll
+          for (int k = 0; k < GB; ++k) pk[k] = v0 + k * S >= pprev ? rt.y + v0 + k * S : pk[k];
+        }
         float4 v[GB];
 #pragma unroll
-        for (int k = 0; k < GB; ++k) v[k] = t4[p + k * L < e ? p + k * L : p];
+        for (int k = 0; k < GB; ++k) v[k] = t4[v0 + k * S < C ? pk[k] : 0];
 #if defined(ICPK_GRID_STAMPS) && !defined(ICPK_GRID_COUNTS)
-        if (v[GB - 1].x == v[GB - 1].x && row == 0 && grid_dbg[wave_id * 8 + 6] == 0) GRID_STAMP(6);  // first batch has arrived
+        if (v[GB - 1].x == v[GB - 1].x && r0 == 0 && grid_dbg[wave_id * 8 + 6] == 0) GRID_STAMP(6);  // first batch has arrived
 #endif
 #pragma unroll
         for (int k = 0; k < GB; ++k) {
           const float dx = qx - v[k].x, dy = qy - v[k].y, dz = qz - v[k].z;
           const float e2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-          if (e2 <= T && p + k * L < e) {
+          if (e2 <= T && v0 + k * S < C) {
             const float d = pair_dist(qx, qy, qz, v[k].x, v[k].y, v[k].z);
             const int jj = __float_as_int(v[k].w);
             const bool up = (d < bd) | ((d == bd) & (jj < bj));
@@ -329,7 +353,7 @@ __global__ __launch_bounds__(ICPK_GRID_BLOCK) void nn_grid_kernel(
     if (S > 1) {
       nn_key_t k2 = ((nn_key_t)__float_as_uint(bd) << 32) | (nn_key_t)(unsigned)bj;
 #pragma unroll
-      for (int m = NQ; m < 64; m <<= 1) {  // butterfly: the winner's point travels with its key
+      for (int m = 1; m < S; m <<= 1) {  // butterfly: the winner's point travels with its key
         const nn_key_t o = __shfl_xor(k2, m, 64);
         const float ox_ = __shfl_xor(bx, m, 64), oy_ = __shfl_xor(by, m, 64), oz_ = __shfl_xor(bz, m, 64);
         const bool take = o < k2;
