@@ -46,8 +46,8 @@ def parse():
     ap.add_argument("--workload", default="kinect640x480_30pct",
                     choices=["kinect640x480_30pct", "kinect640x480_dense", "kinect_v2_512x424", "dense1m", "frustum10k"])
     ap.add_argument("--solve", default="reference", choices=["reference", "kabsch", "p2l"])
-    ap.add_argument("--nn-mode", default="pruned", choices=["exact", "filtered", "pruned", "grid"],
-                    help="all three give bit-identical results; pruned is the product default")
+    ap.add_argument("--nn-mode", default="grid", choices=["exact", "filtered", "pruned", "grid"],
+                    help="all four give bit-identical results; grid is the product default")
     ap.add_argument("--shard", default="frames", choices=["frames", "queries"],
                     help="N>1: 'frames' = one frame pair per rank, no per-iteration collective (default, weak "
                          "scaling); 'queries' = ONE pair, queries split over ranks, one 160-byte all-reduce per "
@@ -244,7 +244,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": {"exact": "nn_exact_kernel", "filtered": "nn_filtered_kernel<2>",
-                                    "pruned": "nn_pruned_kernel<4>", "grid": "nn_grid_kernel"}[args.nn_mode],
+                                    "pruned": "nn_pruned_kernel<4>", "grid": "nn_grid_kernel<8,false>"}[args.nn_mode],
                          "avg_launch_ms": avg_nn_s * 1e3, "algorithmic_bytes_per_launch": alg_bytes,
                          "timing": f"two HIP events recorded on the kernel's own stream immediately around every 4th "
                                    f"K1 launch of the timed region ({nn_timed} of {nn_launches} launches; includes "
@@ -252,12 +252,12 @@ def main():
                                    "the same command is in profiles/)",
                          "gpairs_per_s_kernel": nq * nt / avg_nn_s / 1e9,
                          "note": "algorithmic operand bytes of the brute-force scan this kernel replaces "
-                                 "(Nq*Nt*12 + Nq*20); the pruned kernel returns the same result while skipping "
-                                 "target boxes that are out of reach, so this is not physical traffic; see "
+                                 "(Nq*Nt*12 + Nq*20); the grid / pruned kernels return the same result while "
+                                 "only looking at targets within reach, so this is not physical traffic; see "
                                  "roofline_bruteforce for the kernel that evaluates every pair"},
             "stage_ms_per_step": stage_ms,
         }
-        if world == 1 and args.nn_mode == "pruned":
+        if world == 1 and args.nn_mode in ("pruned", "grid"):
             # the same sweep by the brute-force (un-pruned) filtered kernel, for the roofline
             # of the kernel north_star names: every one of the Nq*Nt pairs is evaluated
             ctx.reset_source()

@@ -95,7 +95,7 @@ class ContextSteps:
         from . import binding
 
         self.ctx = ctx
-        self.nn_mode = binding.NN_PRUNED if nn_mode is None else nn_mode
+        self.nn_mode = binding.NN_GRID if nn_mode is None else nn_mode
 
     def nn(self):
         self.ctx.nn(self.nn_mode, fetch=False)

@@ -578,7 +578,7 @@ void icpk_default_params(icpk_params* p) {
   p->max_nn_dist = ICPK_MAX_NN_DISTANCE;
   p->min_pairs = ICPK_MIN_PAIRS;
   p->solve = ICPK_SOLVE_REFERENCE;
-  p->nn_mode = ICPK_NN_PRUNED;  // same results as ICPK_NN_EXACT (tests), fastest
+  p->nn_mode = ICPK_NN_GRID;  // same results as ICPK_NN_EXACT (tests), fastest
   p->last_rotation[0] = p->last_rotation[4] = p->last_rotation[8] = 1.f;
 }
 

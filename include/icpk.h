@@ -63,10 +63,10 @@ extern "C" {
 #define ICPK_NN_EXACT 0    /* literal double-precision distance per pair             */
 #define ICPK_NN_FILTERED 1 /* seeded fp32 filter + exact re-evaluation; same results */
 #define ICPK_NN_PRUNED 2   /* FILTERED + skipping of target tiles whose bounding box is out \
-                              of reach; same results; default                          */
+                              of reach; same results                                   */
 #define ICPK_NN_GRID 3     /* uniform grid over the target: only the cells that meet the cube \
                               [q - r, q + r] around a query with seed distance r are scanned; \
-                              same results                                              */
+                              same results; default                                     */
 
 /* log keys mirrored from SLAM.hpp:4-13 for the optional callback */
 #define ICPK_LOG_NEAREST_NEIGHBOR 0

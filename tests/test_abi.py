@@ -39,7 +39,7 @@ def test_struct_layouts_match_header(lib):
     assert C.sizeof(binding.Params) == 8 * 4 + 12 * 4 + 4 + 4
     assert C.sizeof(binding.Stats) == 6 * 4 + 4 * 4
     p = binding.default_params()
-    assert (p.max_iterations, p.min_pairs, p.solve, p.nn_mode) == (16, 3, 0, binding.NN_PRUNED)
+    assert (p.max_iterations, p.min_pairs, p.solve, p.nn_mode) == (16, 3, 0, binding.NN_GRID)
     assert p.threshold == np.float32(1e-4) and p.max_nn_dist == np.float32(0.75)
     assert list(p.last_rotation) == [1, 0, 0, 0, 1, 0, 0, 0, 1]
 
