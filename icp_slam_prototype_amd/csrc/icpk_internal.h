@@ -163,7 +163,7 @@ void launch_transform_state(float* x, float* y, float* z, int n, const LoopState
 void launch_reduce_final(const double* partial, const int* pcount, int nblocks, int nsum, double* out, hipStream_t s);
 
 // kernels_reduce.hip
-// partial: [RED_MAX_BLOCKS][NSUM_MAX] doubles, pcount: [RED_MAX_BLOCKS] ints,
+// partial: [NSUM_MAX][RED_MAX_BLOCKS] doubles (sum-major: stage 2 reads it coalesced), pcount: [RED_MAX_BLOCKS] ints,
 // out: nsum doubles followed by one int64 count ((NSUM_MAX + 1) x 8 bytes).
 // out == nullptr: only the per-block partials are produced (the device loop sums them
 // in launch_loop_step); stop: device-loop stop flags or nullptr

@@ -40,7 +40,7 @@ __device__ __forceinline__ void tree_stage2(const double* __restrict__ partial, 
   double v[NS];
   int c = 0;
 #pragma unroll
-  for (int s = 0; s < NS; ++s) v[s] = tid < nblocks ? partial[tid * NS + s] : 0.0;
+  for (int s = 0; s < NS; ++s) v[s] = tid < nblocks ? partial[s * RED_MAX_BLOCKS + tid] : 0.0;  // [sum][block]: coalesced
   if (tid < nblocks) c = pcount[tid];
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) {

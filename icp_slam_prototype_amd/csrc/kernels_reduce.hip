@@ -71,7 +71,7 @@ __global__ __launch_bounds__(RED_THREADS) void assoc_reduce_kernel(
     wc[wave] = cnt;
   }
   __syncthreads();
-  if (tid < NSUM) partial[blockIdx.x * NSUM + tid] = ((ws[0][tid] + ws[1][tid]) + ws[2][tid]) + ws[3][tid];
+  if (tid < NSUM) partial[tid * RED_MAX_BLOCKS + blockIdx.x] = ((ws[0][tid] + ws[1][tid]) + ws[2][tid]) + ws[3][tid];
   if (tid == NSUM) pcount[blockIdx.x] = wc[0] + wc[1] + wc[2] + wc[3];
 }
 
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(RED_THREADS) void p2l_reduce_kernel(
     wc[wave] = cnt;
   }
   __syncthreads();
-  if (tid < NP2L) partial[blockIdx.x * NP2L + tid] = ((ws[0][tid] + ws[1][tid]) + ws[2][tid]) + ws[3][tid];
+  if (tid < NP2L) partial[tid * RED_MAX_BLOCKS + blockIdx.x] = ((ws[0][tid] + ws[1][tid]) + ws[2][tid]) + ws[3][tid];
   if (tid == NP2L) pcount[blockIdx.x] = wc[0] + wc[1] + wc[2] + wc[3];
 }
 
