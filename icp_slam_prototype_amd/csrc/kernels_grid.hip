@@ -326,7 +326,9 @@ __global__ __launch_bounds__(ICPK_GRID_BLOCK) void nn_grid_kernel(
         for (int k = 0; k < GB; ++k) {
           const float dx = qx - v[k].x, dy = qy - v[k].y, dz = qz - v[k].z;
           const float e2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-          if (e2 <= T && v0 + k * S < C) {
+          // (the current best itself -- in steady state usually the seed, met again in its cell --
+          // cannot improve on itself: skipping it keeps more waves out of the float64 path)
+          if (e2 <= T && v0 + k * S < C && __float_as_int(v[k].w) != bj) {
             const float d = pair_dist(qx, qy, qz, v[k].x, v[k].y, v[k].z);
             const int jj = __float_as_int(v[k].w);
             const bool up = (d < bd) | ((d == bd) & (jj < bj));
