@@ -269,7 +269,10 @@ __global__ __launch_bounds__(ICPK_GRID_BLOCK) void nn_grid_kernel(
   // candidates of the chunk 0 .. C-1, and lane k evaluates candidates k, k + S, k + 2S, ...,
   // GB of them per round trip, whatever row they are in.  So a chunk costs one trip for its
   // ranges and ceil(C / (S GB)) trips for its candidates, however unevenly the rows are filled.
-  constexpr int GB = 8;
+#ifndef ICPK_GRID_GB
+#define ICPK_GRID_GB 6
+#endif
+  constexpr int GB = ICPK_GRID_GB;
   __shared__ int2 rowtab[64];  // per query and row of the chunk: (inclusive prefix, start - exclusive prefix)
   int2* const tab = &rowtab[lane & ~(S - 1)];
   auto scan_cells = [&](int x0, int x1, int y0, int y1, int z0, int z1) {
