@@ -100,6 +100,12 @@ struct icpk_ctx {
   float4* sp_in = nullptr;   // seeds as points, query Morton order: read by the next grid sweep
   float4* sp_out = nullptr;  // ... written by it
   int qm4_cap = 0;
+  GridInfo grid_host{};      // host copy of *grid_info (read back once per target)
+  int* qcount = nullptr;     // query counting sort by cell: counts and starts, GRID_MAX_CELLS + 1 each
+  int* qstart = nullptr;
+  void* scan_temp = nullptr;
+  size_t scan_temp_bytes = 0;
+  int qperm_kind = 0;        // what qperm holds: 1 Morton order (pruned scan), 2 cell order (grid scan)
   bool grid_chain = false;   // device loop only: the previous sweep was a grid sweep (qm4 / sp_in current)
   int t4_cap = 0;
   bool have_grid = false;  // grid matches tgt
@@ -320,7 +326,8 @@ int prepare_pruned_target(icpk_ctx* ctx, NnBoxes& bx) {
 int prepare_grid_target(icpk_ctx* ctx) {
   const int nt = ctx->tgt.n;
   if (!ctx->grid_info) ICPK_HIP(ctx, hipMalloc((void**)&ctx->grid_info, sizeof(GridInfo)));
-  if (!ctx->grid_bounds) ICPK_HIP(ctx, hipMalloc((void**)&ctx->grid_bounds, 6 * sizeof(float)));
+  if (!ctx->grid_bounds)
+    ICPK_HIP(ctx, hipMalloc((void**)&ctx->grid_bounds, (size_t)GRID_BOUNDS_PARTS * 6 * sizeof(float)));
   if (!ctx->cell_start) ICPK_HIP(ctx, hipMalloc((void**)&ctx->cell_start, ((size_t)GRID_MAX_CELLS + 1) * sizeof(int)));
   if (nt > ctx->t4_cap) {
     if (ctx->t4) ICPK_HIP(ctx, hipFree(ctx->t4));
@@ -346,7 +353,40 @@ int prepare_grid_target(icpk_ctx* ctx) {
   launch_grid_gather(ctx->tgt.x(), ctx->tgt.y(), ctx->tgt.z(), ctx->grid_perm, nt, ctx->t4, ctx->stream);
   launch_grid_starts(kb, nt, ctx->grid_info, ctx->cell_start, ctx->stream);
   ICPK_HIP(ctx, hipGetLastError());
+  // the host needs the grid's size to dimension the per-alignment query ordering (set-up path:
+  // one 36-byte read-back and a stream sync per target cloud)
+  ICPK_HIP(ctx, hipMemcpyAsync(&ctx->grid_host, ctx->grid_info, sizeof(GridInfo), hipMemcpyDeviceToHost, ctx->stream));
+  ICPK_HIP(ctx, hipStreamSynchronize(ctx->stream));
   ctx->have_grid = true;
+  return ICPK_OK;
+}
+
+// query order for the grid scan: counting sort of the source by cell of the target's grid
+int enqueue_cell_order(icpk_ctx* ctx) {
+  const int nq = ctx->src.n;
+  const int ncells = ctx->grid_host.ncells;
+  if (ncells < 1 || ncells > GRID_MAX_CELLS) return fail(ctx, ICPK_E_HIP, "grid info not available");
+  int rc = ensure_sort_buffers(ctx, nq);
+  if (rc) return rc;
+  if (!ctx->qcount) ICPK_HIP(ctx, hipMalloc((void**)&ctx->qcount, ((size_t)GRID_MAX_CELLS + 1) * sizeof(int)));
+  if (!ctx->qstart) ICPK_HIP(ctx, hipMalloc((void**)&ctx->qstart, ((size_t)GRID_MAX_CELLS + 1) * sizeof(int)));
+  const size_t need = scan_temp_bytes(ncells);
+  if (need > ctx->scan_temp_bytes) {
+    if (ctx->scan_temp) ICPK_HIP(ctx, hipFree(ctx->scan_temp));
+    ctx->scan_temp = nullptr;
+    ctx->scan_temp_bytes = 0;
+    ICPK_HIP(ctx, hipMalloc(&ctx->scan_temp, need));
+    ctx->scan_temp_bytes = need;
+  }
+  int* qcell = reinterpret_cast<int*>(ctx->sort_keys + ctx->sort_cap);
+  int* qslot = ctx->sort_vals;
+  ICPK_HIP(ctx, hipMemsetAsync(ctx->qcount, 0, (size_t)ncells * sizeof(int), ctx->stream));
+  launch_grid_qslot(ctx->src.x(), ctx->src.y(), ctx->src.z(), nq, ctx->grid_info, ctx->qcount, qcell, qslot,
+                    ctx->stream);
+  if (launch_exclusive_scan(ctx->scan_temp, ctx->scan_temp_bytes, ctx->qcount, ctx->qstart, ncells, ctx->stream) != 0)
+    return fail(ctx, ICPK_E_HIP, "rocprim::exclusive_scan failed");
+  launch_grid_qscatter(qcell, qslot, ctx->qstart, nq, ctx->qperm, ctx->stream);
+  ICPK_HIP(ctx, hipGetLastError());
   return ICPK_OK;
 }
 
@@ -408,12 +448,25 @@ int enqueue_nn(icpk_ctx* ctx, int nn_mode, hipEvent_t ev0 = nullptr, hipEvent_t 
       if (rc) return rc;
     }
     bool new_order = false;
-    if (!ctx->have_qperm || !ctx->have_seed) {
-      // query order = Morton order of the source at its current pose (once per alignment);
-      // the unsorted query keys stay in sort_keys[0..nq)
-      rc = enqueue_morton_order(ctx, ctx->src, ctx->qperm);
+    const int want_kind = nn_mode == ICPK_NN_GRID ? 2 : 1;
+    if (!ctx->have_qperm || !ctx->have_seed || ctx->qperm_kind != want_kind) {
+      // query order (once per alignment), from the source at its current pose: Morton order
+      // for the pruned scan, order by grid cell (a cheaper counting sort) for the grid scan.
+      // Either way the unsorted Morton keys of the queries stay in sort_keys[0..nq) for the
+      // first-sweep seeds.
+      if (nn_mode == ICPK_NN_GRID) {
+        rc = ensure_sort_buffers(ctx, nq);
+        if (rc) return rc;
+        if (!ctx->have_seed)
+          launch_morton(ctx->src.x(), ctx->src.y(), ctx->src.z(), nq, ctx->bounds, ctx->sort_keys, ctx->sort_vals,
+                        ctx->stream);
+        rc = enqueue_cell_order(ctx);
+      } else {
+        rc = enqueue_morton_order(ctx, ctx->src, ctx->qperm);
+      }
       if (rc) return rc;
       ctx->have_qperm = true;
+      ctx->qperm_kind = want_kind;
       new_order = true;
     }
     int recheck = 0;
@@ -630,7 +683,7 @@ void icpk_destroy(icpk_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   for (hipEvent_t e : ctx->events) (void)hipEventDestroy(e);
-  void* dev[] = {ctx->qm4, ctx->sp_in, ctx->sp_out, ctx->grid_info, ctx->grid_bounds, ctx->cell_start, ctx->t4, ctx->grid_perm, ctx->best_m, ctx->seed_m, ctx->st_dev, ctx->sorted.base, ctx->tkeys, ctx->tperm, ctx->qperm, ctx->bounds, ctx->sort_keys, ctx->sort_vals, ctx->sort_temp,
+  void* dev[] = {ctx->qcount, ctx->qstart, ctx->scan_temp, ctx->qm4, ctx->sp_in, ctx->sp_out, ctx->grid_info, ctx->grid_bounds, ctx->cell_start, ctx->t4, ctx->grid_perm, ctx->best_m, ctx->seed_m, ctx->st_dev, ctx->sorted.base, ctx->tkeys, ctx->tperm, ctx->qperm, ctx->bounds, ctx->sort_keys, ctx->sort_vals, ctx->sort_temp,
                  ctx->nrm.base, ctx->boxes, ctx->dec.base, ctx->tgt.base, ctx->src0.base, ctx->src.base, ctx->best,      ctx->seed,     ctx->idx,
                  ctx->dist,     ctx->partial,   ctx->pcount,   ctx->red_out,   ctx->depth_dev, ctx->bp_counts};
   for (void* p : dev)

@@ -99,6 +99,7 @@ void launch_decimate(const float* x, const float* y, const float* z, int n, int 
                      int n_out_pad, hipStream_t s);
 // kernels_grid.hip: uniform grid over the target (ICPK_NN_GRID)
 constexpr int GRID_MAX_CELLS = 1 << 22;
+constexpr int GRID_BOUNDS_PARTS = 64;  // partial boxes of the bounds pass (6 floats each)
 struct GridInfo {
   float lo[3];  // finite lower corner of the target
   float inv_h;  // 1 / cell edge
@@ -112,6 +113,11 @@ void launch_grid_cid(const float* x, const float* y, const float* z, int n, cons
                      int* vals, hipStream_t s);
 void launch_grid_gather(const float* x, const float* y, const float* z, const int* perm, int n, float4* t4,
                         hipStream_t s);
+void launch_grid_qslot(const float* x, const float* y, const float* z, int n, const GridInfo* g, int* count, int* qcell,
+                       int* qslot, hipStream_t s);
+void launch_grid_qscatter(const int* qcell, const int* qslot, const int* qstart, int n, int* qperm, hipStream_t s);
+size_t scan_temp_bytes(int n);
+int launch_exclusive_scan(void* temp, size_t temp_bytes, const int* in, int* out, int n, hipStream_t s);
 void launch_grid_starts(const unsigned* sorted_cid, int n, const GridInfo* g, int* cell_start, hipStream_t s);
 void launch_nn_grid(const NnArgs& a, float4* qm4, const float4* t4, const int* cell_start, const GridInfo* g,
                     const float* ox, const float* oy, const float* oz, const float4* sp_in, float4* sp_out,

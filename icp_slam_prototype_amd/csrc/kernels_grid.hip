@@ -31,7 +31,7 @@ __global__ __launch_bounds__(1024) void grid_bounds_kernel(const float* __restri
   for (int c = 0; c < 3; ++c) {
     lo[c] = __builtin_inff();
     hi[c] = -__builtin_inff();
-    for (int i = threadIdx.x; i < n; i += 1024) {
+    for (int i = blockIdx.x * 1024 + threadIdx.x; i < n; i += gridDim.x * 1024) {
       const float v = p[c][i];
       if (v - v == 0.f) {
         lo[c] = __builtin_fminf(lo[c], v);
@@ -53,14 +53,21 @@ __global__ __launch_bounds__(1024) void grid_bounds_kernel(const float* __restri
     float v = red[threadIdx.x][0];
     for (int k = 1; k < 16; ++k)
       v = threadIdx.x < 3 ? __builtin_fminf(v, red[threadIdx.x][k]) : __builtin_fmaxf(v, red[threadIdx.x][k]);
-    fb[threadIdx.x] = v;
+    fb[blockIdx.x * 6 + threadIdx.x] = v;  // one partial box per block; grid_info_kernel merges them
   }
 }
 
 // cell edge: about `ppc` targets per occupied cell if the cloud is a surface whose area is
 // of the order of the bounding box's faces (a depth image is); never more than
 // GRID_MAX_CELLS cells.  Only efficiency depends on the choice.
-__global__ void grid_info_kernel(const float* __restrict__ fb, int n, float ppc, GridInfo* __restrict__ g) {
+__global__ void grid_info_kernel(const float* __restrict__ fbp, int nparts, int n, float ppc,
+                                 GridInfo* __restrict__ g) {
+  float fb[6];
+  for (int c = 0; c < 6; ++c) {
+    float v = fbp[c];
+    for (int b = 1; b < nparts; ++b) v = c < 3 ? __builtin_fminf(v, fbp[b * 6 + c]) : __builtin_fmaxf(v, fbp[b * 6 + c]);
+    fb[c] = v;
+  }
   float lo[3], ext[3];
   float emax = 0.f;
   for (int c = 0; c < 3; ++c) {
@@ -139,11 +146,48 @@ __global__ void grid_starts_kernel(const unsigned* __restrict__ sorted_cid, int 
   cell_start[c] = lo;
 }
 
+// Query order for the grid scan: by cell of the target's grid (counting sort).  Only locality
+// depends on it -- results are scattered back by original index -- so the order inside a
+// cell may be whatever the atomics make it.
+__global__ void grid_qslot_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                  const float* __restrict__ z, int n, const GridInfo* __restrict__ gi,
+                                  int* __restrict__ count, int* __restrict__ qcell, int* __restrict__ qslot) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const GridInfo g = *gi;
+  const int cx = grid_cell(x[i], g.lo[0], g.inv_h, g.nx);
+  const int cy = grid_cell(y[i], g.lo[1], g.inv_h, g.ny);
+  const int cz = grid_cell(z[i], g.lo[2], g.inv_h, g.nz);
+  const int c = (cz * g.ny + cy) * g.nx + cx;
+  qcell[i] = c;
+  qslot[i] = atomicAdd(&count[c], 1);
+}
+
+__global__ void grid_qscatter_kernel(const int* __restrict__ qcell, const int* __restrict__ qslot,
+                                     const int* __restrict__ qstart, int n, int* __restrict__ qperm) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) qperm[qstart[qcell[i]] + qslot[i]] = i;
+}
+
+void launch_grid_qslot(const float* x, const float* y, const float* z, int n, const GridInfo* g, int* count, int* qcell,
+                       int* qslot, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(grid_qslot_kernel, dim3((n + 255) / 256), dim3(256), 0, s, x, y, z, n, g, count, qcell, qslot);
+}
+void launch_grid_qscatter(const int* qcell, const int* qslot, const int* qstart, int n, int* qperm, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(grid_qscatter_kernel, dim3((n + 255) / 256), dim3(256), 0, s, qcell, qslot, qstart, n, qperm);
+}
+
+int grid_bounds_parts(int n) {
+  int nb = (n + 16383) / 16384;
+  return nb < 1 ? 1 : (nb > GRID_BOUNDS_PARTS ? GRID_BOUNDS_PARTS : nb);
+}
 void launch_grid_bounds(const float* x, const float* y, const float* z, int n, float* fb, hipStream_t s) {
-  hipLaunchKernelGGL(grid_bounds_kernel, dim3(1), dim3(1024), 0, s, x, y, z, n, fb);
+  hipLaunchKernelGGL(grid_bounds_kernel, dim3(grid_bounds_parts(n)), dim3(1024), 0, s, x, y, z, n, fb);
 }
 void launch_grid_info(const float* fb, int n, float ppc, GridInfo* g, hipStream_t s) {
-  hipLaunchKernelGGL(grid_info_kernel, dim3(1), dim3(1), 0, s, fb, n, ppc, g);
+  hipLaunchKernelGGL(grid_info_kernel, dim3(1), dim3(1), 0, s, fb, grid_bounds_parts(n), n, ppc, g);
 }
 void launch_grid_cid(const float* x, const float* y, const float* z, int n, const GridInfo* g, unsigned* keys,
                      int* vals, hipStream_t s) {
