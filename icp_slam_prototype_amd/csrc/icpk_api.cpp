@@ -440,26 +440,23 @@ int enqueue_nn(icpk_ctx* ctx, int nn_mode, hipEvent_t ev0 = nullptr, hipEvent_t 
       ctx->qperm_cap = round_up(nq, NN_TILE);
       ctx->have_qperm = false;
     }
-    NnBoxes bx;
-    rc = prepare_pruned_target(ctx, bx);  // Morton order and first-sweep seeds are shared with the grid scan
-    if (rc) return rc;
+    NnBoxes bx{};
     if (nn_mode == ICPK_NN_GRID) {
+      bx.ox = ctx->tgt.x();
+      bx.oy = ctx->tgt.y();
+      bx.oz = ctx->tgt.z();
       rc = prepare_grid_target(ctx);
-      if (rc) return rc;
+    } else {
+      rc = prepare_pruned_target(ctx, bx);
     }
+    if (rc) return rc;
     bool new_order = false;
     const int want_kind = nn_mode == ICPK_NN_GRID ? 2 : 1;
     if (!ctx->have_qperm || !ctx->have_seed || ctx->qperm_kind != want_kind) {
       // query order (once per alignment), from the source at its current pose: Morton order
-      // for the pruned scan, order by grid cell (a cheaper counting sort) for the grid scan.
-      // Either way the unsorted Morton keys of the queries stay in sort_keys[0..nq) for the
-      // first-sweep seeds.
+      // for the pruned scan (the unsorted Morton keys of the queries stay in sort_keys[0..nq)
+      // for its first-sweep seeds), order by grid cell (a cheaper counting sort) for the grid scan
       if (nn_mode == ICPK_NN_GRID) {
-        rc = ensure_sort_buffers(ctx, nq);
-        if (rc) return rc;
-        if (!ctx->have_seed)
-          launch_morton(ctx->src.x(), ctx->src.y(), ctx->src.z(), nq, ctx->bounds, ctx->sort_keys, ctx->sort_vals,
-                        ctx->stream);
         rc = enqueue_cell_order(ctx);
       } else {
         rc = enqueue_morton_order(ctx, ctx->src, ctx->qperm);
@@ -483,6 +480,11 @@ int enqueue_nn(icpk_ctx* ctx, int nn_mode, hipEvent_t ev0 = nullptr, hipEvent_t 
       nn_key_t* t = ctx->seed;
       ctx->seed = ctx->best;
       ctx->best = t;
+    } else if (nn_mode == ICPK_NN_GRID) {
+      // first sweep of the grid scan: the reference's own literal seed, element 0 (icp.cpp:572);
+      // the expanding search does not depend on the seed's quality
+      launch_fill_u64(ctx->seed_m, nq, 0ull, nullptr, ctx->stream);
+      recheck = 1;
     } else {  // first sweep: the target with the nearest Morton code; loose, so re-check lazily
       launch_seed_morton(ctx->sort_keys, ctx->qperm, nq, ctx->src.x(), ctx->src.y(), ctx->src.z(), ctx->tkeys,
                          ctx->sorted.x(), ctx->sorted.y(), ctx->sorted.z(), ctx->tperm, ctx->tgt.n, ctx->seed_m,
