@@ -826,3 +826,75 @@ def test_lopsided_sizes_exact_vs_pruned(ctx, nq, nt):
     T2, s2, _ = ctx.align(max_iterations=2, fixed_iterations=1, solve=binding.SOLVE_KABSCH, nn_mode=binding.NN_EXACT,
                           host_loop=1)
     assert np.array_equal(T1, T2) and s1.final_pairs == s2.final_pairs
+
+
+# ------------------------------------------------------------- grid scan (K1d) --
+def _grid_vs_exact(ctx, src, tgt, sweeps=2):
+    ctx.set_target(tgt)
+    ctx.set_source(src)
+    ie, de = ctx.nn(binding.NN_EXACT)
+    for _ in range(sweeps):  # first sweep (expanding search from element 0), then seeded
+        ig, dg = ctx.nn(binding.NN_GRID)
+        assert np.array_equal(ie, ig) and np.array_equal(de.view(np.uint32), dg.view(np.uint32))
+    return ie, de
+
+
+def test_grid_degenerate_target_shapes(ctx, oracle):
+    """Grids that collapse: one cell (identical targets), one row (collinear), one slab
+    (coplanar), a single target, two far clusters (cells holding thousands of points)."""
+    rng = np.random.default_rng(5)
+    src = (rng.uniform(-1, 1, (3, 3000)) + 5).astype(np.float32)
+    same = np.tile(np.array([[5.0], [5.5], [4.5]], np.float32), (1, 700))
+    line = np.stack([np.linspace(4, 6, 5000), np.full(5000, 5.0), np.full(5000, 5.0)]).astype(np.float32)
+    plane = np.stack([rng.uniform(4, 6, 20000), rng.uniform(4, 6, 20000), np.full(20000, 5.25)]).astype(np.float32)
+    one = np.array([[4.0], [5.0], [6.0]], np.float32)
+    two = np.concatenate([rng.normal(0, 0.01, (3, 4000)) + 5, rng.normal(0, 0.01, (3, 4000)) + 500], 1).astype(np.float32)
+    for tgt in (same, line, plane, one, two):
+        ie, de = _grid_vs_exact(ctx, src, tgt)
+        oi, od = oracle.nn_bruteforce(src, tgt, threads=oracle.max_threads())
+        assert np.array_equal(ie, oi) and np.array_equal(de.view(np.uint32), od.view(np.uint32))
+
+
+def test_grid_queries_outside_and_on_cell_boundaries(ctx):
+    rng = np.random.default_rng(6)
+    tgt = (rng.uniform(0, 1, (3, 30000))).astype(np.float32)
+    far = (rng.uniform(-50, 50, (3, 2000))).astype(np.float32)          # mostly outside the grid
+    lattice = (rng.integers(0, 65, (3, 4000)) / np.float32(64)).astype(np.float32)  # on round coordinates
+    edge = tgt[:, :1000].copy()                                          # queries that ARE targets
+    _grid_vs_exact(ctx, np.concatenate([far, lattice, edge], 1), tgt, sweeps=3)
+
+
+def test_grid_non_finite_targets(ctx):
+    """NaN / inf targets away from index 0 can never be selected; finite queries keep the
+    brute-force answer."""
+    rng = np.random.default_rng(8)
+    tgt = rng.uniform(-2, 2, (3, 6000)).astype(np.float32)
+    tgt[0, 17] = np.nan
+    tgt[1, 900] = np.inf
+    tgt[2, 5999] = -np.inf
+    src = rng.uniform(-2, 2, (3, 2500)).astype(np.float32)
+    ie, de = _grid_vs_exact(ctx, src, tgt)
+    assert not np.isin(ie, [17, 900, 5999]).any() and np.isfinite(de).all()
+
+
+@pytest.mark.parametrize("env", [{"ICPK_GRID_SLICES": "1"}, {"ICPK_GRID_SLICES": "2"}, {"ICPK_GRID_SLICES": "4"},
+                                 {"ICPK_GRID_PPC": "0.25"}, {"ICPK_GRID_PPC": "400"}])
+def test_grid_tuning_knobs_do_not_change_results(env, monkeypatch):
+    """Lanes per query and cell size are performance knobs only (read at context creation)."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    c = binding.Context(0)
+    try:
+        p = synth.kinect_pair(rows=120, cols=160, seed=5)
+        c.set_target(p["target"])
+        c.set_source(p["source"])
+        ie, de = c.nn(binding.NN_EXACT)
+        c.reset_source()
+        for _ in range(2):
+            ig, dg = c.nn(binding.NN_GRID)
+            assert np.array_equal(ie, ig) and np.array_equal(de.view(np.uint32), dg.view(np.uint32))
+        T1, s1, _ = c.align(max_iterations=4, fixed_iterations=1, nn_mode=binding.NN_GRID)
+        T2, s2, _ = c.align(max_iterations=4, fixed_iterations=1, nn_mode=binding.NN_EXACT)
+        assert np.array_equal(T1, T2) and s1.final_pairs == s2.final_pairs
+    finally:
+        c.close()
