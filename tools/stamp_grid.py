@@ -28,6 +28,10 @@ for first in (True, False):
         ok = (b[:, a] > 0) & (b[:, c] > 0)
         v = (b[ok, c] - b[ok, a]) * 10.0
         print(f"  {name:7s} ns: mean {v.mean():8.0f} p50 {np.median(v):8.0f} p90 {np.quantile(v, 0.9):8.0f} max {v.max():8.0f}")
+    en = (b[:, 4] - t0) * 10.0
+    print("  wave end ns: " + " ".join(f"p{int(q*100)} {np.quantile(en, q):.0f}" for q in (0.5, 0.9, 0.99, 0.999, 1.0)))
+    tot = (b[:, 4] - b[:, 0]) * 10.0
+    print(f"  busy fraction of {7 * 1024} slots x span: {tot.sum() / (7 * 1024 * en.max()):.2f}")
     st = (b[:, 0] - t0) * 10.0
     print(f"  wave start ns: p50 {np.median(st):.0f} p90 {np.quantile(st, 0.9):.0f} max {st.max():.0f}")
 
