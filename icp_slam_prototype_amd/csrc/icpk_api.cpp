@@ -95,7 +95,6 @@ struct icpk_ctx {
   float* grid_bounds = nullptr;
   int* cell_start = nullptr;  // GRID_MAX_CELLS + 1
   float4* t4 = nullptr;
-  int* grid_perm = nullptr;  // sorted position -> original index
   float4* qm4 = nullptr;     // queries in Morton order (x, y, z, original index)
   float4* sp_in = nullptr;   // seeds as points, query Morton order: read by the next grid sweep
   float4* sp_out = nullptr;  // ... written by it
@@ -323,6 +322,20 @@ int prepare_pruned_target(icpk_ctx* ctx, NnBoxes& bx) {
 }
 
 // cell table + cell-sorted AoS copy of the target for the grid scan (once per target cloud)
+int ensure_scan_buffers(icpk_ctx* ctx, int n) {
+  if (!ctx->qcount) ICPK_HIP(ctx, hipMalloc((void**)&ctx->qcount, ((size_t)GRID_MAX_CELLS + 1) * sizeof(int)));
+  if (!ctx->qstart) ICPK_HIP(ctx, hipMalloc((void**)&ctx->qstart, ((size_t)GRID_MAX_CELLS + 1) * sizeof(int)));
+  const size_t need = scan_temp_bytes(n);
+  if (need > ctx->scan_temp_bytes) {
+    if (ctx->scan_temp) ICPK_HIP(ctx, hipFree(ctx->scan_temp));
+    ctx->scan_temp = nullptr;
+    ctx->scan_temp_bytes = 0;
+    ICPK_HIP(ctx, hipMalloc(&ctx->scan_temp, need));
+    ctx->scan_temp_bytes = need;
+  }
+  return ICPK_OK;
+}
+
 int prepare_grid_target(icpk_ctx* ctx) {
   const int nt = ctx->tgt.n;
   if (!ctx->grid_info) ICPK_HIP(ctx, hipMalloc((void**)&ctx->grid_info, sizeof(GridInfo)));
@@ -334,9 +347,6 @@ int prepare_grid_target(icpk_ctx* ctx) {
     ctx->t4 = nullptr;
     ctx->t4_cap = 0;
     ICPK_HIP(ctx, hipMalloc((void**)&ctx->t4, ((size_t)round_up(nt, NN_TILE) + 64) * sizeof(float4)));
-    if (ctx->grid_perm) ICPK_HIP(ctx, hipFree(ctx->grid_perm));
-    ctx->grid_perm = nullptr;
-    ICPK_HIP(ctx, hipMalloc((void**)&ctx->grid_perm, ((size_t)round_up(nt, NN_TILE) + 64) * sizeof(int)));
     ctx->t4_cap = round_up(nt, NN_TILE);
     ctx->have_grid = false;
   }
@@ -345,18 +355,28 @@ int prepare_grid_target(icpk_ctx* ctx) {
   if (rc) return rc;
   launch_grid_bounds(ctx->tgt.x(), ctx->tgt.y(), ctx->tgt.z(), nt, ctx->grid_bounds, ctx->stream);
   launch_grid_info(ctx->grid_bounds, nt, ctx->grid_ppc, ctx->grid_info, ctx->stream);
-  unsigned* ka = ctx->sort_keys;
-  unsigned* kb = ctx->sort_keys + ctx->sort_cap;
-  launch_grid_cid(ctx->tgt.x(), ctx->tgt.y(), ctx->tgt.z(), nt, ctx->grid_info, ka, ctx->sort_vals, ctx->stream);
-  if (launch_sort_pairs(ctx->sort_temp, ctx->sort_temp_bytes, ka, kb, ctx->sort_vals, ctx->grid_perm, nt, ctx->stream) != 0)
-    return fail(ctx, ICPK_E_HIP, "rocprim::radix_sort_pairs failed");
-  launch_grid_gather(ctx->tgt.x(), ctx->tgt.y(), ctx->tgt.z(), ctx->grid_perm, nt, ctx->t4, ctx->stream);
-  launch_grid_starts(kb, nt, ctx->grid_info, ctx->cell_start, ctx->stream);
-  ICPK_HIP(ctx, hipGetLastError());
-  // the host needs the grid's size to dimension the per-alignment query ordering (set-up path:
-  // one 36-byte read-back and a stream sync per target cloud)
+  // the host needs the grid's size to dimension the counting sorts (set-up path: one 36-byte
+  // read-back and a stream sync per target cloud)
   ICPK_HIP(ctx, hipMemcpyAsync(&ctx->grid_host, ctx->grid_info, sizeof(GridInfo), hipMemcpyDeviceToHost, ctx->stream));
   ICPK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  const int ncells = ctx->grid_host.ncells;
+  if (ncells < 1 || ncells > GRID_MAX_CELLS) return fail(ctx, ICPK_E_HIP, "grid info not available");
+  rc = ensure_scan_buffers(ctx, ncells + 1);
+  if (rc) return rc;
+  // counting sort of the targets by cell: slot within the cell by atomics (the order inside a
+  // cell is irrelevant: candidates are merged lexicographically), cell starts by an exclusive
+  // scan of the counts (entry ncells = Nt), scatter into the AoS copy
+  int* tcell = reinterpret_cast<int*>(ctx->sort_keys + ctx->sort_cap);
+  int* tslot = ctx->sort_vals;
+  ICPK_HIP(ctx, hipMemsetAsync(ctx->qcount, 0, ((size_t)ncells + 1) * sizeof(int), ctx->stream));
+  launch_grid_qslot(ctx->tgt.x(), ctx->tgt.y(), ctx->tgt.z(), nt, ctx->grid_info, ctx->qcount, tcell, tslot,
+                    ctx->stream);
+  if (launch_exclusive_scan(ctx->scan_temp, ctx->scan_temp_bytes, ctx->qcount, ctx->cell_start, ncells + 1,
+                            ctx->stream) != 0)
+    return fail(ctx, ICPK_E_HIP, "rocprim::exclusive_scan failed");
+  launch_grid_tscatter(ctx->tgt.x(), ctx->tgt.y(), ctx->tgt.z(), tcell, tslot, ctx->cell_start, nt, ctx->t4,
+                       ctx->stream);
+  ICPK_HIP(ctx, hipGetLastError());
   ctx->have_grid = true;
   return ICPK_OK;
 }
@@ -368,16 +388,8 @@ int enqueue_cell_order(icpk_ctx* ctx) {
   if (ncells < 1 || ncells > GRID_MAX_CELLS) return fail(ctx, ICPK_E_HIP, "grid info not available");
   int rc = ensure_sort_buffers(ctx, nq);
   if (rc) return rc;
-  if (!ctx->qcount) ICPK_HIP(ctx, hipMalloc((void**)&ctx->qcount, ((size_t)GRID_MAX_CELLS + 1) * sizeof(int)));
-  if (!ctx->qstart) ICPK_HIP(ctx, hipMalloc((void**)&ctx->qstart, ((size_t)GRID_MAX_CELLS + 1) * sizeof(int)));
-  const size_t need = scan_temp_bytes(ncells);
-  if (need > ctx->scan_temp_bytes) {
-    if (ctx->scan_temp) ICPK_HIP(ctx, hipFree(ctx->scan_temp));
-    ctx->scan_temp = nullptr;
-    ctx->scan_temp_bytes = 0;
-    ICPK_HIP(ctx, hipMalloc(&ctx->scan_temp, need));
-    ctx->scan_temp_bytes = need;
-  }
+  rc = ensure_scan_buffers(ctx, ncells);
+  if (rc) return rc;
   int* qcell = reinterpret_cast<int*>(ctx->sort_keys + ctx->sort_cap);
   int* qslot = ctx->sort_vals;
   ICPK_HIP(ctx, hipMemsetAsync(ctx->qcount, 0, (size_t)ncells * sizeof(int), ctx->stream));
@@ -685,7 +697,7 @@ void icpk_destroy(icpk_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   for (hipEvent_t e : ctx->events) (void)hipEventDestroy(e);
-  void* dev[] = {ctx->qcount, ctx->qstart, ctx->scan_temp, ctx->qm4, ctx->sp_in, ctx->sp_out, ctx->grid_info, ctx->grid_bounds, ctx->cell_start, ctx->t4, ctx->grid_perm, ctx->best_m, ctx->seed_m, ctx->st_dev, ctx->sorted.base, ctx->tkeys, ctx->tperm, ctx->qperm, ctx->bounds, ctx->sort_keys, ctx->sort_vals, ctx->sort_temp,
+  void* dev[] = {ctx->qcount, ctx->qstart, ctx->scan_temp, ctx->qm4, ctx->sp_in, ctx->sp_out, ctx->grid_info, ctx->grid_bounds, ctx->cell_start, ctx->t4, ctx->best_m, ctx->seed_m, ctx->st_dev, ctx->sorted.base, ctx->tkeys, ctx->tperm, ctx->qperm, ctx->bounds, ctx->sort_keys, ctx->sort_vals, ctx->sort_temp,
                  ctx->nrm.base, ctx->boxes, ctx->dec.base, ctx->tgt.base, ctx->src0.base, ctx->src.base, ctx->best,      ctx->seed,     ctx->idx,
                  ctx->dist,     ctx->partial,   ctx->pcount,   ctx->red_out,   ctx->depth_dev, ctx->bp_counts};
   for (void* p : dev)

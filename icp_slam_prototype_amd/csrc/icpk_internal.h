@@ -109,16 +109,13 @@ struct GridInfo {
 };
 void launch_grid_bounds(const float* x, const float* y, const float* z, int n, float* fb, hipStream_t s);
 void launch_grid_info(const float* fb, int n, float ppc, GridInfo* g, hipStream_t s);
-void launch_grid_cid(const float* x, const float* y, const float* z, int n, const GridInfo* g, unsigned* keys,
-                     int* vals, hipStream_t s);
-void launch_grid_gather(const float* x, const float* y, const float* z, const int* perm, int n, float4* t4,
-                        hipStream_t s);
+void launch_grid_tscatter(const float* x, const float* y, const float* z, const int* tcell, const int* tslot,
+                          const int* cell_start, int n, float4* t4, hipStream_t s);
 void launch_grid_qslot(const float* x, const float* y, const float* z, int n, const GridInfo* g, int* count, int* qcell,
                        int* qslot, hipStream_t s);
 void launch_grid_qscatter(const int* qcell, const int* qslot, const int* qstart, int n, int* qperm, hipStream_t s);
 size_t scan_temp_bytes(int n);
 int launch_exclusive_scan(void* temp, size_t temp_bytes, const int* in, int* out, int n, hipStream_t s);
-void launch_grid_starts(const unsigned* sorted_cid, int n, const GridInfo* g, int* cell_start, hipStream_t s);
 void launch_nn_grid(const NnArgs& a, float4* qm4, const float4* t4, const int* cell_start, const GridInfo* g,
                     const float* ox, const float* oy, const float* oz, const float4* sp_in, float4* sp_out,
                     nn_key_t* best_m, int slices, int expand, const LoopState* st, hipStream_t s);

@@ -11,8 +11,9 @@
 // re-evaluation + lexicographic (distance, index) merge as the other kernels, and the cell
 // cube is a superset of every target that could tie or beat the seed (see cube_cells).
 //
-// Set-up (once per target cloud): finite bounds, cell size from the point density, cell ids,
-// rocPRIM radix sort, AoS gather (x, y, z, original index in one 16-byte load), cell starts.
+// Set-up (once per target cloud): finite bounds, cell size from the point density, counting
+// sort by cell (atomics + rocPRIM exclusive scan = the cell starts) into an AoS copy
+// (x, y, z, original index: one 16-byte load per candidate).
 #include "icpk_internal.h"
 #include "nn_device.h"
 
@@ -111,44 +112,10 @@ __device__ __forceinline__ int grid_cell(float v, float lo, float inv_h, int n) 
   return (int)f;
 }
 
-__global__ void grid_cid_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z,
-                                int n, const GridInfo* __restrict__ gi, unsigned* __restrict__ keys,
-                                int* __restrict__ vals) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const GridInfo g = *gi;
-  const int cx = grid_cell(x[i], g.lo[0], g.inv_h, g.nx);
-  const int cy = grid_cell(y[i], g.lo[1], g.inv_h, g.ny);
-  const int cz = grid_cell(z[i], g.lo[2], g.inv_h, g.nz);
-  keys[i] = (unsigned)((cz * g.ny + cy) * g.nx + cx);
-  vals[i] = i;
-}
-
-__global__ void grid_gather_kernel(const float* __restrict__ x, const float* __restrict__ y,
-                                   const float* __restrict__ z, const int* __restrict__ perm, int n,
-                                   float4* __restrict__ t4) {
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= n) return;
-  const int j = perm[p];
-  t4[p] = make_float4(x[j], y[j], z[j], __int_as_float(j));
-}
-
-// cell_start[c] = first sorted position whose cell id is >= c, for c = 0 .. ncells
-__global__ void grid_starts_kernel(const unsigned* __restrict__ sorted_cid, int n, const GridInfo* __restrict__ gi,
-                                   int* __restrict__ cell_start) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c > gi->ncells) return;
-  int lo = 0, hi = n;
-  while (lo < hi) {
-    const int mid = (lo + hi) >> 1;
-    if (sorted_cid[mid] < (unsigned)c) lo = mid + 1; else hi = mid;
-  }
-  cell_start[c] = lo;
-}
-
-// Query order for the grid scan: by cell of the target's grid (counting sort).  Only locality
-// depends on it -- results are scattered back by original index -- so the order inside a
-// cell may be whatever the atomics make it.
+// Counting sort by cell, used for the targets (set-up) and for the query order (once per
+// alignment): slot within the cell by atomics -- the order inside a cell may be whatever the
+// atomics make it: target candidates are merged lexicographically, and the query order only
+// matters for locality (results are scattered back by original index).
 __global__ void grid_qslot_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                   const float* __restrict__ z, int n, const GridInfo* __restrict__ gi,
                                   int* __restrict__ count, int* __restrict__ qcell, int* __restrict__ qslot) {
@@ -167,6 +134,22 @@ __global__ void grid_qscatter_kernel(const int* __restrict__ qcell, const int* _
                                      const int* __restrict__ qstart, int n, int* __restrict__ qperm) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) qperm[qstart[qcell[i]] + qslot[i]] = i;
+}
+
+// targets into the AoS copy (x, y, z, original index), one 16-byte load per candidate
+__global__ void grid_tscatter_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                     const float* __restrict__ z, const int* __restrict__ tcell,
+                                     const int* __restrict__ tslot, const int* __restrict__ cell_start, int n,
+                                     float4* __restrict__ t4) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) t4[cell_start[tcell[i]] + tslot[i]] = make_float4(x[i], y[i], z[i], __int_as_float(i));
+}
+
+void launch_grid_tscatter(const float* x, const float* y, const float* z, const int* tcell, const int* tslot,
+                          const int* cell_start, int n, float4* t4, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(grid_tscatter_kernel, dim3((n + 255) / 256), dim3(256), 0, s, x, y, z, tcell, tslot, cell_start,
+                     n, t4);
 }
 
 void launch_grid_qslot(const float* x, const float* y, const float* z, int n, const GridInfo* g, int* count, int* qcell,
@@ -188,20 +171,6 @@ void launch_grid_bounds(const float* x, const float* y, const float* z, int n, f
 }
 void launch_grid_info(const float* fb, int n, float ppc, GridInfo* g, hipStream_t s) {
   hipLaunchKernelGGL(grid_info_kernel, dim3(1), dim3(1), 0, s, fb, grid_bounds_parts(n), n, ppc, g);
-}
-void launch_grid_cid(const float* x, const float* y, const float* z, int n, const GridInfo* g, unsigned* keys,
-                     int* vals, hipStream_t s) {
-  if (n <= 0) return;
-  hipLaunchKernelGGL(grid_cid_kernel, dim3((n + 255) / 256), dim3(256), 0, s, x, y, z, n, g, keys, vals);
-}
-void launch_grid_gather(const float* x, const float* y, const float* z, const int* perm, int n, float4* t4,
-                        hipStream_t s) {
-  if (n <= 0) return;
-  hipLaunchKernelGGL(grid_gather_kernel, dim3((n + 255) / 256), dim3(256), 0, s, x, y, z, perm, n, t4);
-}
-void launch_grid_starts(const unsigned* sorted_cid, int n, const GridInfo* g, int* cell_start, hipStream_t s) {
-  hipLaunchKernelGGL(grid_starts_kernel, dim3((GRID_MAX_CELLS + 1 + 255) / 256), dim3(256), 0, s, sorted_cid, n, g,
-                     cell_start);
 }
 
 // ---- the sweep --------------------------------------------------------------------------
