@@ -290,11 +290,7 @@ __global__ __launch_bounds__(ICPK_GRID_BLOCK) void nn_grid_kernel(
   int2* const tab = &rowtab[lane & ~(S - 1)];
   auto scan_cells = [&](int x0, int x1, int y0, int y1, int z0, int z1) {
     const int nyr = y1 - y0 + 1;
-#ifdef ICPK_GRID_NOSCAN
-    const int nrows = 0;
-#else
     const int nrows = scan ? nyr * (z1 - z0 + 1) : 0;
-#endif
     if (slice == 0) GRID_COUNT(5, nrows);
     for (int r0 = 0; r0 < nrows; r0 += S) {
       const int row = r0 + slice;
