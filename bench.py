@@ -244,10 +244,11 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": {"exact": "nn_exact_kernel", "filtered": "nn_filtered_kernel<2>",
-                                    "pruned": "nn_pruned_kernel<4>", "grid": "nn_grid_kernel<8,false>"}[args.nn_mode],
+                                    "pruned": "nn_pruned_kernel<4>", "grid": "nn_grid_kernel<8,false|true>"}[args.nn_mode],
                          "avg_launch_ms": avg_nn_s * 1e3, "algorithmic_bytes_per_launch": alg_bytes,
                          "timing": f"two HIP events recorded on the kernel's own stream immediately around every 4th "
-                                   f"K1 launch of the timed region ({nn_timed} of {nn_launches} launches; includes "
+                                   f"K1 launch of the timed region, the offset advancing with every alignment ({nn_timed} of "
+                                   f"{nn_launches} launches, first sweeps in proportion; includes "
                                    "~5 us of dispatch latency per launch; the rocprofv3 --kernel-trace average of "
                                    "the same command is in profiles/)",
                          "gpairs_per_s_kernel": nq * nt / avg_nn_s / 1e9,

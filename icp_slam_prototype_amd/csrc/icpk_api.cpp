@@ -104,6 +104,7 @@ struct icpk_ctx {
   int* qstart = nullptr;
   void* scan_temp = nullptr;
   size_t scan_temp_bytes = 0;
+  int profile_phase = 0;     // alignments profiled so far (offsets the sampled launches, see profile_stride)
   int qperm_kind = 0;        // what qperm holds: 1 Morton order (pruned scan), 2 cell order (grid scan)
   bool grid_chain = false;   // device loop only: the previous sweep was a grid sweep (qm4 / sp_in current)
   int t4_cap = 0;
@@ -929,10 +930,11 @@ static int align_device_loop(icpk_ctx* ctx, const icpk_params* p, float T_out[16
 
   std::vector<nn_key_t*> best_of_sweep;
   int nsweep = 0;
+  const int phase = ctx->profile_phase++;  // successive alignments bracket different sweeps: unbiased sample
   auto sweep = [&]() -> int {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     const int nth = nsweep++;
-    if (prof && (prof_all || p->profile_stride <= 1 || nth % p->profile_stride == 0)) {
+    if (prof && (prof_all || p->profile_stride <= 1 || (nth + phase) % p->profile_stride == 0)) {
       // two events tightly around the K1 launch
       e0 = get_event(ctx, nev);
       e1 = get_event(ctx, nev + 1);
@@ -1107,10 +1109,11 @@ int icpk_align(icpk_ctx* ctx, const icpk_params* p, float T_out[16], icpk_stats*
   float mse = 0.f;
   int sweeps = 0;
   int nsweep = 0;
+  const int phase = ctx->profile_phase++;  // successive alignments bracket different sweeps: unbiased sample
   auto sweep = [&]() -> int {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     const int nth = nsweep++;
-    if (prof && (prof_all || p->profile_stride <= 1 || nth % p->profile_stride == 0)) {
+    if (prof && (prof_all || p->profile_stride <= 1 || (nth + phase) % p->profile_stride == 0)) {
       // two events tightly around the K1 launch
       e0 = get_event(ctx, nev);
       e1 = get_event(ctx, nev + 1);

@@ -105,8 +105,10 @@ typedef struct icpk_params {
                                and the loop test / solve run on the device (no host round
                                trip per iteration); 1: the host drives each iteration and
                                solves (one 160-byte read-back per iteration).  Same results. */
-  int32_t profile_stride;   /* profile == 1 only: bracket every n-th NN launch (0, 1: every one);
-                               an event pair costs ~4 us of queue time, which a 40 us kernel notices */
+  int32_t profile_stride;   /* profile == 1 only: bracket every n-th NN launch (0, 1: every one;
+                               the offset advances with every alignment, so the sample covers all
+                               sweep positions); an event pair costs ~4 us of queue time, which a
+                               20 us kernel notices */
 } icpk_params;
 
 typedef struct icpk_stats {
