@@ -11,6 +11,7 @@
 // K3 then reads its transform from the state instead of kernel arguments.
 #include "icpk_internal.h"
 #include "solve_impl.h"
+#include "wave_sum.h"
 
 namespace icpk {
 
@@ -42,12 +43,7 @@ __device__ __forceinline__ void tree_stage2(const double* __restrict__ partial, 
 #pragma unroll
   for (int s = 0; s < NS; ++s) v[s] = tid < nblocks ? partial[s * RED_MAX_BLOCKS + tid] : 0.0;  // [sum][block]: coalesced
   if (tid < nblocks) c = pcount[tid];
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) {
-#pragma unroll
-    for (int s = 0; s < NS; ++s) v[s] += __shfl_xor(v[s], m, 64);
-    c += __shfl_xor(c, m, 64);
-  }
+  wave_butterfly<NS>(v, c);
   if (lane == 0) {
 #pragma unroll
     for (int s = 0; s < NS; ++s) ws[wave][s] = v[s];

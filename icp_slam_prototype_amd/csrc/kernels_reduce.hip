@@ -12,8 +12,23 @@
 // order -- no atomics, so results are bit-reproducible and equal to the
 // oracle's orc_sums_canonical.
 #include "icpk_internal.h"
+#include "wave_sum.h"
 
 namespace icpk {
+
+// Diagnostic build only (-DICPK_RED_STAMPS, tools/stamp_reduce.py): wall_clock64 stamps per block
+#ifdef ICPK_RED_STAMPS
+__device__ unsigned long long red_dbg[8 * 256];
+#define RED_STAMP(k)                                                               \
+  do {                                                                             \
+    if (threadIdx.x == 0) red_dbg[blockIdx.x * 8 + (k)] = wall_clock64();          \
+  } while (0)
+extern "C" int icpk_debug_read_red_stamps(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(red_dbg), sizeof(red_dbg));
+}
+#else
+#define RED_STAMP(k)
+#endif
 
 __global__ __launch_bounds__(RED_THREADS) void assoc_reduce_kernel(
     const nn_key_t* __restrict__ best, const float* __restrict__ ax, const float* __restrict__ ay,
@@ -26,6 +41,7 @@ __global__ __launch_bounds__(RED_THREADS) void assoc_reduce_kernel(
   }
   const int tid = threadIdx.x;
   const int P = gridDim.x * RED_THREADS;
+  RED_STAMP(0);
   double v[NSUM];
 #pragma unroll
   for (int s = 0; s < NSUM; ++s) v[s] = 0.0;
@@ -54,13 +70,10 @@ __global__ __launch_bounds__(RED_THREADS) void assoc_reduce_kernel(
     }
   }
 
+  if (v[12] > -1.0) RED_STAMP(1);  // loads and accumulation done
   // wave64 butterfly: every lane ends with the same value; order 32,16,...,1
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) {
-#pragma unroll
-    for (int s = 0; s < NSUM; ++s) v[s] += __shfl_xor(v[s], m, 64);
-    cnt += __shfl_xor(cnt, m, 64);
-  }
+  wave_butterfly<NSUM>(v, cnt);
+  if (v[12] > -1.0) RED_STAMP(2);  // butterfly done
 
   __shared__ double ws[RED_THREADS / 64][NSUM];
   __shared__ int wc[RED_THREADS / 64];
@@ -73,6 +86,7 @@ __global__ __launch_bounds__(RED_THREADS) void assoc_reduce_kernel(
   __syncthreads();
   if (tid < NSUM) partial[tid * RED_MAX_BLOCKS + blockIdx.x] = ((ws[0][tid] + ws[1][tid]) + ws[2][tid]) + ws[3][tid];
   if (tid == NSUM) pcount[blockIdx.x] = wc[0] + wc[1] + wc[2] + wc[3];
+  RED_STAMP(3);
 }
 
 // K5: normal equations of the linearised point-to-plane step (extension; the
@@ -126,12 +140,7 @@ __global__ __launch_bounds__(RED_THREADS) void p2l_reduce_kernel(
       }
     }
   }
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) {
-#pragma unroll
-    for (int s = 0; s < NP2L; ++s) v[s] += __shfl_xor(v[s], m, 64);
-    cnt += __shfl_xor(cnt, m, 64);
-  }
+  wave_butterfly<NP2L>(v, cnt);
   __shared__ double ws[RED_THREADS / 64][NP2L];
   __shared__ int wc[RED_THREADS / 64];
   const int wave = tid >> 6, lane = tid & 63;
