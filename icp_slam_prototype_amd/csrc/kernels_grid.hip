@@ -14,8 +14,11 @@
 // Set-up (once per target cloud): finite bounds, cell size from the point density, counting
 // sort by cell (atomics + rocPRIM exclusive scan = the cell starts) into an AoS copy
 // (x, y, z, original index: one 16-byte load per candidate).
+#include <type_traits>
+
 #include "icpk_internal.h"
 #include "nn_device.h"
+#include "wave_sum.h"
 
 namespace icpk {
 
@@ -303,13 +306,24 @@ __global__ __launch_bounds__(ICPK_GRID_BLOCK) void nn_grid_kernel(
         len = cell_start[base + x1 + 1] - s0;
       }
       GRID_COUNT(6, len);
-      int P = len;
-#pragma unroll
-      for (int d = 1; d < S; d <<= 1) {
-        const int o = __shfl_up(P, d, 64);
-        if (slice >= d) P += o;
+      // inclusive prefix and total over the S adjacent lanes: DPP moves inside the row of 16
+      // (the S lanes of a query are active or inactive together, so every source lane is live)
+      int P = len, C = len;
+      if constexpr (S >= 2) {
+        const int o = dpp_mov<0x111>(P);  // row_shr:1
+        if (slice >= 1) P += o;
+        C += xor_lane<1>(C);
       }
-      const int C = __shfl(P, lane | (S - 1), 64);
+      if constexpr (S >= 4) {
+        const int o = dpp_mov<0x112>(P);  // row_shr:2
+        if (slice >= 2) P += o;
+        C += xor_lane<2>(C);
+      }
+      if constexpr (S >= 8) {
+        const int o = dpp_mov<0x114>(P);  // row_shr:4
+        if (slice >= 4) P += o;
+        C += xor_lane<4>(C);
+      }
       __builtin_amdgcn_wave_barrier();  // the previous chunk's table has been read
       tab[slice] = make_int2(P, s0 - (P - len));
       __builtin_amdgcn_wave_barrier();  // (one wave per workgroup: LDS operations complete in order)
@@ -366,16 +380,22 @@ __global__ __launch_bounds__(ICPK_GRID_BLOCK) void nn_grid_kernel(
   auto share = [&]() {  // the S lanes of a query agree on the best (distance, index, point) so far
     if (S > 1) {
       nn_key_t k2 = ((nn_key_t)__float_as_uint(bd) << 32) | (nn_key_t)(unsigned)bj;
-#pragma unroll
-      for (int m = 1; m < S; m <<= 1) {  // butterfly: the winner's point travels with its key
-        const nn_key_t o = __shfl_xor(k2, m, 64);
-        const float ox_ = __shfl_xor(bx, m, 64), oy_ = __shfl_xor(by, m, 64), oz_ = __shfl_xor(bz, m, 64);
+      auto step = [&](auto mc) {  // butterfly: the winner's point travels with its key
+        constexpr int M = decltype(mc)::value;
+        const nn_key_t o = ((nn_key_t)(unsigned)xor_lane<M>((int)(unsigned)(k2 >> 32)) << 32) |
+                           (nn_key_t)(unsigned)xor_lane<M>((int)(unsigned)(k2 & 0xffffffffu));
+        const float ox_ = __int_as_float(xor_lane<M>(__float_as_int(bx)));
+        const float oy_ = __int_as_float(xor_lane<M>(__float_as_int(by)));
+        const float oz_ = __int_as_float(xor_lane<M>(__float_as_int(bz)));
         const bool take = o < k2;
         k2 = take ? o : k2;
         bx = take ? ox_ : bx;
         by = take ? oy_ : by;
         bz = take ? oz_ : bz;
-      }
+      };
+      if constexpr (S >= 2) step(std::integral_constant<int, 1>{});
+      if constexpr (S >= 4) step(std::integral_constant<int, 2>{});
+      if constexpr (S >= 8) step(std::integral_constant<int, 4>{});
       if (scan) {  // (a NaN distance is not ordered by its bits; such lanes never scan)
         bd = __uint_as_float((unsigned)(k2 >> 32));
         bj = (int)(unsigned)(k2 & 0xffffffffu);
