@@ -95,8 +95,8 @@ struct icpk_ctx {
   float* grid_bounds = nullptr;
   int* cell_start = nullptr;  // GRID_MAX_CELLS + 1
   float4* t4 = nullptr;
-  float4* qm4 = nullptr;     // queries in Morton order (x, y, z, original index)
-  float4* sp_in = nullptr;   // seeds as points, query Morton order: read by the next grid sweep
+  float4* qm4 = nullptr;     // queries in scan order (x, y, z, original index)
+  float4* sp_in = nullptr;   // seeds as points, scan order: read by the next grid sweep
   float4* sp_out = nullptr;  // ... written by it
   int qm4_cap = 0;
   GridInfo grid_host{};      // host copy of *grid_info (read back once per target)

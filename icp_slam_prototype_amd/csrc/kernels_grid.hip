@@ -188,9 +188,8 @@ __device__ __forceinline__ void cube_cells(float q, float r, float lo, float inv
   c1 = grid_cell(q + rr, lo, inv_h, n);
 }
 
-// S lanes per query (rows of the cube dealt round-robin); the rest of the interface is the
-// pruned kernel's: queries in Morton order (neighbouring lanes read neighbouring cells),
-// seeds / results in that order too, K3 fused in device-loop mode.
+// S adjacent lanes per query; queries in cell order (neighbouring queries read the same
+// rows), seeds / results in that order too, K3 fused in device-loop mode.
 // Diagnostic build only (tools/stamp_grid.py, -DICPK_GRID_STAMPS): per-wave wall_clock64
 // (100 MHz) stamps of the phases and work counters.
 #ifdef ICPK_GRID_STAMPS
@@ -227,10 +226,11 @@ __global__ __launch_bounds__(ICPK_GRID_BLOCK) void nn_grid_kernel(
     const float* __restrict__ oxp, const float* __restrict__ oyp, const float* __restrict__ ozp,
     const float4* __restrict__ sp_in, float4* __restrict__ sp_out, nn_key_t* __restrict__ best,
     nn_key_t* __restrict__ best_m, const LoopState* __restrict__ st) {
-  // qm4: the queries in Morton order, (x, y, z, original index) -- one coalesced 16-byte load
-  // instead of the qperm -> coordinates chain; kept in step with the caller's planes here.
-  // sp_in / sp_out: the seed of every query as a point (x, y, z, target index), again in query
-  // Morton order: the match of the previous sweep, written by that sweep.
+  // qm4: the queries in scan order (by grid cell), (x, y, z, original index) -- one coalesced
+  // 16-byte load instead of the qperm -> coordinates chain; kept in step with the caller's
+  // planes here.  sp_in / sp_out: the seed of every query as a point (x, y, z, target index) in
+  // the same order: the match of the previous sweep, written by that sweep.  best_m: the
+  // results in scan order (seeds of a following sweep that does not continue the chain).
   bool apply_rt = false, stop_after = false;
   if (st) {
     if (st->done) return;
