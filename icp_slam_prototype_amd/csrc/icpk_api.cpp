@@ -104,6 +104,7 @@ struct icpk_ctx {
   int* qstart = nullptr;
   void* scan_temp = nullptr;
   size_t scan_temp_bytes = 0;
+  int loop_nact = NSUM;      // device loop: sums the running alignment's step consumes (NSUM_REF or NSUM)
   int profile_phase = 0;     // alignments profiled so far (offsets the sampled launches, see profile_stride)
   int qperm_kind = 0;        // what qperm holds: 1 Morton order (pruned scan), 2 cell order (grid scan)
   bool grid_chain = false;   // device loop only: the previous sweep was a grid sweep (qm4 / sp_in current)
@@ -602,7 +603,7 @@ int enqueue_reduce(icpk_ctx* ctx, float max_dist) {
   const int nq = ctx->src.n;
   launch_assoc_reduce(ctx->best, ctx->src.x(), ctx->src.y(), ctx->src.z(), nq, ctx->tgt.x(), ctx->tgt.y(), ctx->tgt.z(),
                       max_dist, ctx->idx, ctx->dist, ctx->partial, ctx->pcount, ctx->st_active ? nullptr : ctx->red_out,
-                      ctx->st_active, ctx->stream);
+                      ctx->st_active, ctx->st_active ? ctx->loop_nact : NSUM, ctx->stream);
   ICPK_HIP(ctx, hipGetLastError());
   if (!ctx->st_active)
     ICPK_HIP(ctx, hipMemcpyAsync(ctx->red_host, ctx->red_out, (NSUM + 1) * sizeof(double), hipMemcpyDeviceToHost,
@@ -890,7 +891,9 @@ static int align_device_loop(icpk_ctx* ctx, const icpk_params* p, float T_out[16
   const bool prof_all = p->profile >= 2;  // 1: NN kernels only (2 events per sweep); 2: every stage
   const bool p2l = p->solve == ICPK_SOLVE_POINT_TO_PLANE;
   const bool fused = p->nn_mode == ICPK_NN_PRUNED || p->nn_mode == ICPK_NN_GRID;  // K3 runs inside the sweep
-  const int nsum = p2l ? NP2L : NSUM;
+  // the reference flavour's step reads sums [0..12] only: K2 and stage 2 skip the rest
+  const int nsum = p2l ? NP2L : (p->solve == ICPK_SOLVE_REFERENCE ? NSUM_REF : NSUM);
+  ctx->loop_nact = nsum == NSUM_REF ? NSUM_REF : NSUM;
   const int B = red_blocks(ctx->src.n);
   size_t nev = 0;
   std::vector<size_t> ev_nn, ev_red, ev_tr;

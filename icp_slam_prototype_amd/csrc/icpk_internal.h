@@ -41,6 +41,7 @@ struct Rt {
 struct LoopState;  // device-side loop state, defined below
 
 constexpr int NSUM = 19;
+constexpr int NSUM_REF = 13;  // sums [0..12]: all the reference flavour's loop step reads
 constexpr int NP2L = 28;      // point-to-plane: 21 + 6 + 1
 constexpr int NSUM_MAX = 28;
 constexpr int RED_THREADS = 256;
@@ -172,7 +173,8 @@ void launch_reduce_final(const double* partial, const int* pcount, int nblocks, 
 // in launch_loop_step); stop: device-loop stop flags or nullptr
 void launch_assoc_reduce(const nn_key_t* best, const float* ax, const float* ay, const float* az, int nq,
                          const float* tx, const float* ty, const float* tz, float max_dist, int32_t* idx_out,
-                         float* dist_out, double* partial, int* pcount, double* out, LoopState* st, hipStream_t s);
+                         float* dist_out, double* partial, int* pcount, double* out, LoopState* st, int nact,
+                         hipStream_t s);
 
 void launch_p2l_reduce(const nn_key_t* best, const float* ax, const float* ay, const float* az, int nq, const float* tx,
                        const float* ty, const float* tz, const float* nx, const float* ny, const float* nz,

@@ -32,27 +32,28 @@ extern "C" int icpk_debug_read_step_stamps(unsigned long long* out) {
 
 // canonical stage 2: 256 slots (slot b = sums of block b, +0.0 beyond nblocks), one slot
 // per lane; wave butterfly, ((w0+w1)+w2)+w3.  Result in sums[] of thread 0.
-template <int NS>
+template <int NS, int NACT = NS>
 __device__ __forceinline__ void tree_stage2(const double* __restrict__ partial, const int* __restrict__ pcount,
                                             int nblocks, double (&sums)[NS], long long& count) {
-  __shared__ double ws[4][NS];
+  // only the first NACT sums were produced (and are consumed); the others read as 0
+  __shared__ double ws[4][NACT];
   __shared__ int wc[4];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  double v[NS];
+  double v[NACT];
   int c = 0;
 #pragma unroll
-  for (int s = 0; s < NS; ++s) v[s] = tid < nblocks ? partial[s * RED_MAX_BLOCKS + tid] : 0.0;  // [sum][block]: coalesced
+  for (int s = 0; s < NACT; ++s) v[s] = tid < nblocks ? partial[s * RED_MAX_BLOCKS + tid] : 0.0;  // [sum][block]: coalesced
   if (tid < nblocks) c = pcount[tid];
-  wave_butterfly<NS>(v, c);
+  wave_butterfly<NACT>(v, c);
   if (lane == 0) {
 #pragma unroll
-    for (int s = 0; s < NS; ++s) ws[wave][s] = v[s];
+    for (int s = 0; s < NACT; ++s) ws[wave][s] = v[s];
     wc[wave] = c;
   }
   __syncthreads();
   if (tid == 0) {
 #pragma unroll
-    for (int s = 0; s < NS; ++s) sums[s] = ((ws[0][s] + ws[1][s]) + ws[2][s]) + ws[3][s];
+    for (int s = 0; s < NS; ++s) sums[s] = s < NACT ? ((ws[0][s] + ws[1][s]) + ws[2][s]) + ws[3][s] : 0.0;
     count = (long long)wc[0] + wc[1] + wc[2] + wc[3];
   }
 }
@@ -89,7 +90,7 @@ __device__ void compose_rt(const float Rf[9], const float tf[3], double Tk[12]) 
   for (int k = 0; k < 12; ++k) Tk[k] = Tn[k];
 }
 
-template <int NS>
+template <int NS, int NACT = NS>
 __global__ __launch_bounds__(256) void loop_step_kernel(const double* __restrict__ partial,
                                                         const int* __restrict__ pcount, int nblocks,
                                                         LoopState* __restrict__ st, int stats_only) {
@@ -195,6 +196,9 @@ void launch_loop_step(const double* partial, const int* pcount, int nblocks, int
                       hipStream_t s) {
   if (nsum == NP2L)
     hipLaunchKernelGGL(loop_step_kernel<NP2L>, dim3(1), dim3(256), 0, s, partial, pcount, nblocks, st, stats_only);
+  else if (nsum == NSUM_REF)  // reference flavour: the reduction produced sums [0..12] only
+    hipLaunchKernelGGL((loop_step_kernel<NSUM, NSUM_REF>), dim3(1), dim3(256), 0, s, partial, pcount, nblocks, st,
+                       stats_only);
   else
     hipLaunchKernelGGL(loop_step_kernel<NSUM>, dim3(1), dim3(256), 0, s, partial, pcount, nblocks, st, stats_only);
 }

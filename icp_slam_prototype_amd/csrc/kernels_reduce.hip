@@ -30,6 +30,10 @@ extern "C" int icpk_debug_read_red_stamps(unsigned long long* out) {
 #define RED_STAMP(k)
 #endif
 
+// NACT: how many of the NSUM sums the consumer needs.  icpk_reduce and the Kabsch flavour take
+// all 19; the reference flavour's loop step only reads [0..12] (M, mean difference, distance
+// sum), so the device loop skips the sums of a and b: a third less butterfly.
+template <int NACT>
 __global__ __launch_bounds__(RED_THREADS) void assoc_reduce_kernel(
     const nn_key_t* __restrict__ best, const float* __restrict__ ax, const float* __restrict__ ay,
     const float* __restrict__ az, int nq, const float* __restrict__ tx, const float* __restrict__ ty,
@@ -42,9 +46,9 @@ __global__ __launch_bounds__(RED_THREADS) void assoc_reduce_kernel(
   const int tid = threadIdx.x;
   const int P = gridDim.x * RED_THREADS;
   RED_STAMP(0);
-  double v[NSUM];
+  double v[NACT];
 #pragma unroll
-  for (int s = 0; s < NSUM; ++s) v[s] = 0.0;
+  for (int s = 0; s < NACT; ++s) v[s] = 0.0;
   int cnt = 0;
 
   for (int i = blockIdx.x * RED_THREADS + tid; i < nq; i += P) {
@@ -64,28 +68,30 @@ __global__ __launch_bounds__(RED_THREADS) void assoc_reduce_kernel(
       v[10] += (double)(a1 - b1);
       v[11] += (double)(a2 - b2);
       v[12] += (double)d;
-      v[13] += da0; v[14] += da1; v[15] += da2;
-      v[16] += db0; v[17] += db1; v[18] += db2;
+      if constexpr (NACT > 13) {
+        v[13] += da0; v[14] += da1; v[15] += da2;
+        v[16] += db0; v[17] += db1; v[18] += db2;
+      }
       ++cnt;
     }
   }
 
   if (v[12] > -1.0) RED_STAMP(1);  // loads and accumulation done
   // wave64 butterfly: every lane ends with the same value; order 32,16,...,1
-  wave_butterfly<NSUM>(v, cnt);
+  wave_butterfly<NACT>(v, cnt);
   if (v[12] > -1.0) RED_STAMP(2);  // butterfly done
 
-  __shared__ double ws[RED_THREADS / 64][NSUM];
+  __shared__ double ws[RED_THREADS / 64][NACT];
   __shared__ int wc[RED_THREADS / 64];
   const int wave = tid >> 6, lane = tid & 63;
   if (lane == 0) {
 #pragma unroll
-    for (int s = 0; s < NSUM; ++s) ws[wave][s] = v[s];
+    for (int s = 0; s < NACT; ++s) ws[wave][s] = v[s];
     wc[wave] = cnt;
   }
   __syncthreads();
-  if (tid < NSUM) partial[tid * RED_MAX_BLOCKS + blockIdx.x] = ((ws[0][tid] + ws[1][tid]) + ws[2][tid]) + ws[3][tid];
-  if (tid == NSUM) pcount[blockIdx.x] = wc[0] + wc[1] + wc[2] + wc[3];
+  if (tid < NACT) partial[tid * RED_MAX_BLOCKS + blockIdx.x] = ((ws[0][tid] + ws[1][tid]) + ws[2][tid]) + ws[3][tid];
+  if (tid == NACT) pcount[blockIdx.x] = wc[0] + wc[1] + wc[2] + wc[3];
   RED_STAMP(3);
 }
 
@@ -166,10 +172,15 @@ void launch_p2l_reduce(const nn_key_t* best, const float* ax, const float* ay, c
 
 void launch_assoc_reduce(const nn_key_t* best, const float* ax, const float* ay, const float* az, int nq,
                          const float* tx, const float* ty, const float* tz, float max_dist, int32_t* idx_out,
-                         float* dist_out, double* partial, int* pcount, double* out, LoopState* st, hipStream_t s) {
+                         float* dist_out, double* partial, int* pcount, double* out, LoopState* st, int nact,
+                         hipStream_t s) {
   const int B = red_blocks(nq);
-  hipLaunchKernelGGL(assoc_reduce_kernel, dim3(B), dim3(RED_THREADS), 0, s, best, ax, ay, az, nq, tx, ty, tz,
-                     max_dist, idx_out, dist_out, partial, pcount, st);
+  if (nact == NSUM_REF && !out)
+    hipLaunchKernelGGL(assoc_reduce_kernel<NSUM_REF>, dim3(B), dim3(RED_THREADS), 0, s, best, ax, ay, az, nq, tx, ty, tz,
+                       max_dist, idx_out, dist_out, partial, pcount, st);
+  else
+    hipLaunchKernelGGL(assoc_reduce_kernel<NSUM>, dim3(B), dim3(RED_THREADS), 0, s, best, ax, ay, az, nq, tx, ty, tz,
+                       max_dist, idx_out, dist_out, partial, pcount, st);
   if (out) launch_reduce_final(partial, pcount, B, NSUM, out, s);
 }
 
