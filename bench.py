@@ -184,10 +184,11 @@ def main():
     _, st2, _ = ctx.align(params)
     stage_ms = {"nn": st2.nn_ms_total, "reduce": st2.reduce_ms_total, "transform": st2.transform_ms_total,
                 "total": st2.total_ms}
-    # timed region: every 4th K1 launch is bracketed by two HIP events (an event pair costs
-    # ~4 us of queue time per launch, ~8 % of an iteration when every launch carries one)
+    # timed region: every 7th K1 launch is bracketed by two HIP events, the offset rotating
+    # from alignment to alignment so that all 21 sweep positions are sampled evenly (an event
+    # pair costs ~4 us of queue time: ~10 % of an iteration if every launch carried one)
     params.profile = 1
-    params.profile_stride = 4
+    params.profile_stride = 7
     sync_all()
     t0 = time.perf_counter()
     nn_ms = 0.0
@@ -246,7 +247,7 @@ def main():
                          "kernel": {"exact": "nn_exact_kernel", "filtered": "nn_filtered_kernel<2>",
                                     "pruned": "nn_pruned_kernel<4>", "grid": "nn_grid_kernel<8,false|true>"}[args.nn_mode],
                          "avg_launch_ms": avg_nn_s * 1e3, "algorithmic_bytes_per_launch": alg_bytes,
-                         "timing": f"two HIP events recorded on the kernel's own stream immediately around every 4th "
+                         "timing": f"two HIP events recorded on the kernel's own stream immediately around every 7th "
                                    f"K1 launch of the timed region, the offset advancing with every alignment ({nn_timed} of "
                                    f"{nn_launches} launches, first sweeps in proportion; includes "
                                    "~5 us of dispatch latency per launch; the rocprofv3 --kernel-trace average of "
