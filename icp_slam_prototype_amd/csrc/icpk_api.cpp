@@ -602,7 +602,8 @@ int enqueue_nn(icpk_ctx* ctx, int nn_mode, hipEvent_t ev0 = nullptr, hipEvent_t 
 int enqueue_reduce(icpk_ctx* ctx, float max_dist) {
   const int nq = ctx->src.n;
   launch_assoc_reduce(ctx->best, ctx->src.x(), ctx->src.y(), ctx->src.z(), nq, ctx->tgt.x(), ctx->tgt.y(), ctx->tgt.z(),
-                      max_dist, ctx->idx, ctx->dist, ctx->partial, ctx->pcount, ctx->st_active ? nullptr : ctx->red_out,
+                      max_dist, ctx->st_active ? nullptr : ctx->idx, ctx->st_active ? nullptr : ctx->dist, ctx->partial,
+                      ctx->pcount, ctx->st_active ? nullptr : ctx->red_out,
                       ctx->st_active, ctx->st_active ? ctx->loop_nact : NSUM, ctx->stream);
   ICPK_HIP(ctx, hipGetLastError());
   if (!ctx->st_active)
@@ -614,7 +615,8 @@ int enqueue_reduce(icpk_ctx* ctx, float max_dist) {
 // point-to-plane flavour of enqueue_reduce (K5)
 int enqueue_reduce_p2l(icpk_ctx* ctx, float max_dist) {
   launch_p2l_reduce(ctx->best, ctx->src.x(), ctx->src.y(), ctx->src.z(), ctx->src.n, ctx->tgt.x(), ctx->tgt.y(),
-                    ctx->tgt.z(), ctx->nrm.x(), ctx->nrm.y(), ctx->nrm.z(), max_dist, ctx->idx, ctx->dist, ctx->partial,
+                    ctx->tgt.z(), ctx->nrm.x(), ctx->nrm.y(), ctx->nrm.z(), max_dist, ctx->st_active ? nullptr : ctx->idx,
+                    ctx->st_active ? nullptr : ctx->dist, ctx->partial,
                     ctx->pcount, ctx->st_active ? nullptr : ctx->red_out, ctx->st_active, ctx->stream);
   ICPK_HIP(ctx, hipGetLastError());
   if (!ctx->st_active)

@@ -55,8 +55,10 @@ __global__ __launch_bounds__(RED_THREADS) void assoc_reduce_kernel(
     const nn_key_t key = best[i];
     const float d = __uint_as_float((unsigned)(key >> 32));
     const int j = (int)(unsigned)(key & 0xffffffffu);
-    idx_out[i] = j;
-    dist_out[i] = d;
+    if (idx_out) {  // (null in the device loop: icpk_get_associations unpacks on demand)
+      idx_out[i] = j;
+      dist_out[i] = d;
+    }
     if (d < max_dist) {  // icp.cpp:553 (false for NaN)
       const float a0 = ax[i], a1 = ay[i], a2 = az[i];
       const float b0 = tx[j], b1 = ty[j], b2 = tz[j];
@@ -119,8 +121,10 @@ __global__ __launch_bounds__(RED_THREADS) void p2l_reduce_kernel(
     const nn_key_t key = best[i];
     const float d = __uint_as_float((unsigned)(key >> 32));
     const int j = (int)(unsigned)(key & 0xffffffffu);
-    idx_out[i] = j;
-    dist_out[i] = d;
+    if (idx_out) {  // (null in the device loop: icpk_get_associations unpacks on demand)
+      idx_out[i] = j;
+      dist_out[i] = d;
+    }
     if (d < max_dist) {
       const double n0 = nxp[j], n1 = nyp[j], n2 = nzp[j];
       if (!(n0 == 0.0 && n1 == 0.0 && n2 == 0.0)) {
