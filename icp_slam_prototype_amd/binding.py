@@ -30,7 +30,7 @@ SYMBOLS = [
     "icpk_nn", "icpk_reduce", "icpk_transform_source", "icpk_transform_target", "icpk_get_trace",
     "icpk_get_associations", "icpk_align",
     "icpk_align_batch", "icpk_backproject", "icpk_backproject_with_normals", "icpk_set_target_normals",
-    "icpk_get_target_normals", "icpk_reduce_p2l", "icpk_solve_point_to_plane", "icpk_pair_distance", "icpk_make_rotation_matrix",
+    "icpk_get_target_normals", "icpk_reduce_p2l", "icpk_solve_point_to_plane", "icpk_pair_distance", "icpk_pair_distance3", "icpk_distance3", "icpk_make_rotation_matrix",
     "icpk_matrix_to_quaternion", "icpk_quaternion_to_euler", "icpk_solve_reference", "icpk_solve_kabsch",
 ]
 
@@ -126,6 +126,9 @@ def load():
     lib.icpk_backproject.argtypes = [C.c_void_p, C.POINTER(C.c_uint16), C.c_int32, C.c_int32, C.c_float, C.c_float,
                                      fp, C.c_int32]
     lib.icpk_pair_distance.argtypes = [C.c_void_p, fp, fp, fp, C.c_int32]
+    lib.icpk_pair_distance3.argtypes = [C.c_void_p, fp, fp, fp, C.c_int32]
+    lib.icpk_distance3.argtypes = [fp, fp]
+    lib.icpk_distance3.restype = C.c_float
     lib.icpk_backproject_with_normals.argtypes = [C.c_void_p, C.POINTER(C.c_uint16), C.c_int32, C.c_int32, C.c_float,
                                                   C.c_float, fp, C.c_int32]
     lib.icpk_set_target_normals.argtypes = [C.c_void_p, fp, fp, fp, C.c_int32]
@@ -189,6 +192,13 @@ def quaternion_to_euler(q):
     e = np.zeros(3, np.float32)
     load().icpk_quaternion_to_euler(_fp(q), _fp(e))
     return e
+
+
+def distance3(a, b):
+    """icp.cpp:595-602 distance(cv::Point3f, cv::Point3f) on the host."""
+    a = _f(a).reshape(3)
+    b = _f(b).reshape(3)
+    return np.float32(load().icpk_distance3(_fp(a), _fp(b)))
 
 
 def solve_reference(M):
@@ -344,12 +354,14 @@ class Context:
         return [dict(R=R[i].reshape(3, 3).copy(), t=t[i].copy(), n_pairs=int(pairs[i]), mse=np.float32(mse[i]))
                 for i in range(k)]
 
-    def pair_distance(self, a, b):
+    def pair_distance(self, a, b, point3=False):
+        """point3: the cv::Point3f overload (icp.cpp:595-602) instead of the loop's distance."""
         a = _f(a)
         b = _f(b)
         n = a.shape[1]
         out = np.empty(n, np.float32)
-        self._chk(self._lib.icpk_pair_distance(self._h, _fp(a), _fp(b), _fp(out), n))
+        fn = self._lib.icpk_pair_distance3 if point3 else self._lib.icpk_pair_distance
+        self._chk(fn(self._h, _fp(a), _fp(b), _fp(out), n))
         return out
 
     def backproject(self, depth, which=0, fx=468.60, cx=318.27, offset=None):

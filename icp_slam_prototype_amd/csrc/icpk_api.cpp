@@ -1443,8 +1443,8 @@ int icpk_solve_point_to_plane(const double sums[28], double R[9], double t[3]) {
   return solve_p2l(sums, R, t) ? ICPK_OK : ICPK_W_DEGENERATE;
 }
 
-/* test hook: icp.cpp:606-620 on n pairs; a and b are host xyz-SoA [3][n] */
-int icpk_pair_distance(icpk_ctx* ctx, const float* a, const float* b, float* out, int32_t n) {
+/* test hook: icp.cpp:606-620 (point3 == 0) or :595-602 (point3 == 1) on n pairs; a and b are host xyz-SoA [3][n] */
+static int pair_distance_impl(icpk_ctx* ctx, const float* a, const float* b, float* out, int32_t n, int point3) {
   if (!ctx || n < 0 || (n > 0 && (!a || !b || !out))) return ICPK_E_ARG;
   if (n == 0) return ICPK_OK;
   ICPK_HIP(ctx, hipSetDevice(ctx->device));
@@ -1454,13 +1454,23 @@ int icpk_pair_distance(icpk_ctx* ctx, const float* a, const float* b, float* out
   ICPK_HIP(ctx, hipMalloc((void**)&dout, (size_t)n * sizeof(float)));
   ICPK_HIP(ctx, hipMemcpyAsync(da, a, (size_t)3 * n * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
   ICPK_HIP(ctx, hipMemcpyAsync(db, b, (size_t)3 * n * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-  launch_pair_distance(da, db, dout, n, ctx->stream);
+  launch_pair_distance(da, db, dout, n, point3, ctx->stream);
   ICPK_HIP(ctx, hipMemcpyAsync(out, dout, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
   ICPK_HIP(ctx, hipStreamSynchronize(ctx->stream));
   (void)hipFree(da);
   (void)hipFree(db);
   (void)hipFree(dout);
   return ICPK_OK;
+}
+
+int icpk_pair_distance(icpk_ctx* ctx, const float* a, const float* b, float* out, int32_t n) {
+  return pair_distance_impl(ctx, a, b, out, n, 0);
+}
+int icpk_pair_distance3(icpk_ctx* ctx, const float* a, const float* b, float* out, int32_t n) {
+  return pair_distance_impl(ctx, a, b, out, n, 1);
+}
+float icpk_distance3(const float a[3], const float b[3]) {
+  return a && b ? distance3(a[0], a[1], a[2], b[0], b[1], b[2]) : __builtin_nanf("");
 }
 
 void icpk_make_rotation_matrix(float x, float y, float z, float out[9]) { make_rotation_matrix(x, y, z, out); }

@@ -117,14 +117,35 @@ void launch_grid_qslot(const float* x, const float* y, const float* z, int n, co
 void launch_grid_qscatter(const int* qcell, const int* qslot, const int* qstart, int n, int* qperm, hipStream_t s);
 size_t scan_temp_bytes(int n);
 int launch_exclusive_scan(void* temp, size_t temp_bytes, const int* in, int* out, int n, hipStream_t s);
-void launch_nn_grid(const NnArgs& a, float4* qm4, const float4* t4, const int* cell_start, const GridInfo* g,
-                    const float* ox, const float* oy, const float* oz, const float4* sp_in, float4* sp_out,
-                    nn_key_t* best_m, int slices, int expand, const LoopState* st, hipStream_t s);
+// one pair's arguments of a grid sweep (K1d); see nn_grid_body
+struct GridSweepArgs {
+  float *qx, *qy, *qz;  // the caller's source planes (kept in step when K3 is fused)
+  int nq;
+  int pad0;
+  float4* qm4;            // queries in scan order (x, y, z, original index)
+  const float4* t4;       // targets sorted by cell (x, y, z, original index)
+  const int* cell_start;
+  const GridInfo* gi;
+  const float *ox, *oy, *oz;  // target in the caller's order (literal seed, element 0)
+  const float4* sp_in;    // seeds as points, scan order
+  float4* sp_out;         // matches as points = the next sweep's seeds
+  nn_key_t* best;         // results, caller's order
+  nn_key_t* best_m;       // results, scan order
+  const LoopState* st;    // device-side loop state (K3 fused) or nullptr
+};
+// frame-batch mode: up to BATCH_MAX independent pairs advance in lock step, one launch per
+// stage for the whole group (blockIdx.y / blockIdx.x = pair); arguments travel by value.
+constexpr int BATCH_MAX = 16;
+struct GridSweepBatch {
+  GridSweepArgs p[BATCH_MAX];
+};
+void launch_nn_grid(const GridSweepArgs& a, int slices, int expand, hipStream_t s);
+void launch_nn_grid_batch(const GridSweepBatch& b, int count, int slices, int expand, hipStream_t s);
 void launch_grid_query_points(const float* qx, const float* qy, const float* qz, const int* qperm, int nq,
                               const nn_key_t* seed_m, const float* ox, const float* oy, const float* oz, float4* qm4,
                               float4* sp, hipStream_t s);
 constexpr int NN_SEED_STRIDE = 16;  // decimation of the target for the seeding pre-pass
-void launch_pair_distance(const float* a, const float* b, float* out, int n, hipStream_t s);
+void launch_pair_distance(const float* a, const float* b, float* out, int n, int point3, hipStream_t s);
 
 // ---- device-side ICP loop (kernels_loop.hip) ------------------------------------
 // One LoopState per context lives in device memory; while an alignment runs, every
@@ -161,8 +182,19 @@ __device__ __forceinline__ bool loop_stopped(const int* stop) { return stop && (
 
 // sums the per-block partials with the canonical tree and, unless stats_only, performs
 // one loop body's host work on the device: exit test, solve, pose accumulation, trace
+struct StepArgs {
+  const double* partial;
+  const int* pcount;
+  int nblocks;
+  int pad0;
+  LoopState* st;
+};
+struct StepBatch {
+  StepArgs p[BATCH_MAX];
+};
 void launch_loop_step(const double* partial, const int* pcount, int nblocks, int nsum, LoopState* st, int stats_only,
                       hipStream_t s);
+void launch_loop_step_batch(const StepBatch& b, int count, int nsum, int stats_only, hipStream_t s);
 void launch_transform_state(float* x, float* y, float* z, int n, const LoopState* st, hipStream_t s);
 void launch_reduce_final(const double* partial, const int* pcount, int nblocks, int nsum, double* out, hipStream_t s);
 
@@ -175,6 +207,21 @@ void launch_assoc_reduce(const nn_key_t* best, const float* ax, const float* ay,
                          const float* tx, const float* ty, const float* tz, float max_dist, int32_t* idx_out,
                          float* dist_out, double* partial, int* pcount, double* out, LoopState* st, int nact,
                          hipStream_t s);
+// one pair's arguments of K2 inside a device loop (no idx/dist unpacking, no final stage)
+struct ReduceArgs {
+  const nn_key_t* best;
+  const float *ax, *ay, *az;
+  const float *tx, *ty, *tz;
+  double* partial;
+  int* pcount;
+  LoopState* st;
+  int nq;
+  int nblocks;  // red_blocks(nq): the canonical geometry of THIS pair
+};
+struct ReduceBatch {
+  ReduceArgs p[BATCH_MAX];
+};
+void launch_assoc_reduce_batch(const ReduceBatch& b, int count, float max_dist, int nact, hipStream_t s);
 
 void launch_p2l_reduce(const nn_key_t* best, const float* ax, const float* ay, const float* az, int nq, const float* tx,
                        const float* ty, const float* tz, const float* nx, const float* ny, const float* nz,

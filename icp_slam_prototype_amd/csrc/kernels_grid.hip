@@ -178,12 +178,19 @@ void launch_grid_info(const float* fb, int n, float ppc, GridInfo* g, hipStream_
 
 // ---- the sweep --------------------------------------------------------------------------
 // Cells met by the cube [q - rr, q + rr], rr slightly above the current best distance r.
-// A target that could tie or beat r has |q_c - t_c| <= r on every axis (its float distance
-// is >= |fl(q_c - t_c)| (1 - 2^-22)); rr = r (1 + 2^-19) + |q_c| 2^-21 + 2^-100 also
-// absorbs the rounding of q_c -/+ rr, so fl(q_c - rr) <= t_c <= fl(q_c + rr) and, grid_cell
-// being monotone, the target's cell lies in [c0, c1].
+// A target t that could tie or beat r has d_t = sqrtf(fl32(S_t)) <= r, S_t the float64 sum of
+// the squared float differences (icp.cpp:606-620).  sqrtf is correctly rounded, so
+// fl32(S_t) <= r^2 (1 + 2^-22); the narrowing of S_t carries a RELATIVE error 2^-24 when the
+// radicand is a normal float but an ABSOLUTE error up to 2^-150 when it is a float denormal,
+// hence S_t <= r^2 (1 + 2^-21) + 2^-150 and, per axis,
+//   |fl(q_c - t_c)| <= sqrt(S_t) <= r (1 + 2^-22) + 2^-75,
+//   |q_c - t_c| <= |fl(q_c - t_c)| (1 + 2^-23)   (exact when the difference is denormal).
+// rr = r (1 + 2^-19) + |q_c| 2^-21 + 2^-74 covers both and absorbs the rounding of
+// q_c -/+ rr, so fl(q_c - rr) <= t_c <= fl(q_c + rr) and, grid_cell being monotone, the
+// target's cell lies in [c0, c1].  (Round 1 used 2^-100 as the absolute term, which is too
+// small below a cloud scale of ~1e-19: sqrt(2^-150) = 2^-75.)
 __device__ __forceinline__ void cube_cells(float q, float r, float lo, float inv_h, int n, int& c0, int& c1) {
-  const float rr = __builtin_fmaf(r, 1.0f + 0x1p-19f, __builtin_fmaf(__builtin_fabsf(q), 0x1p-21f, 0x1p-100f));
+  const float rr = __builtin_fmaf(r, 1.0f + 0x1p-19f, __builtin_fmaf(__builtin_fabsf(q), 0x1p-21f, 0x1p-74f));
   c0 = grid_cell(q - rr, lo, inv_h, n);
   c1 = grid_cell(q + rr, lo, inv_h, n);
 }
@@ -219,13 +226,27 @@ extern "C" int icpk_debug_clear_grid_stamps() {
 #endif
 
 #define ICPK_GRID_BLOCK 64  // one wave per workgroup (the row table in LDS relies on it)
+// The sweep of ONE frame pair by workgroup `block` of its launch.  nn_grid_kernel runs it for
+// a single pair (arguments by value); nn_grid_batch_kernel runs blockIdx.y-many independent
+// pairs in lock step (frame-batch mode): same code, same results.
 template <int S, bool EXPAND>
-__global__ __launch_bounds__(ICPK_GRID_BLOCK) void nn_grid_kernel(
-    float* __restrict__ qxp, float* __restrict__ qyp, float* __restrict__ qzp, int nq, float4* __restrict__ qm4,
-    const float4* __restrict__ t4, const int* __restrict__ cell_start, const GridInfo* __restrict__ gi,
-    const float* __restrict__ oxp, const float* __restrict__ oyp, const float* __restrict__ ozp,
-    const float4* __restrict__ sp_in, float4* __restrict__ sp_out, nn_key_t* __restrict__ best,
-    nn_key_t* __restrict__ best_m, const LoopState* __restrict__ st) {
+__device__ __forceinline__ void nn_grid_body(const GridSweepArgs& ga, const int block) {
+  float* __restrict__ const qxp = ga.qx;
+  float* __restrict__ const qyp = ga.qy;
+  float* __restrict__ const qzp = ga.qz;
+  const int nq = ga.nq;
+  float4* __restrict__ const qm4 = ga.qm4;
+  const float4* __restrict__ const t4 = ga.t4;
+  const int* __restrict__ const cell_start = ga.cell_start;
+  const GridInfo* __restrict__ const gi = ga.gi;
+  const float* __restrict__ const oxp = ga.ox;
+  const float* __restrict__ const oyp = ga.oy;
+  const float* __restrict__ const ozp = ga.oz;
+  const float4* __restrict__ const sp_in = ga.sp_in;
+  float4* __restrict__ const sp_out = ga.sp_out;
+  nn_key_t* __restrict__ const best = ga.best;
+  nn_key_t* __restrict__ const best_m = ga.best_m;
+  const LoopState* __restrict__ const st = ga.st;
   // qm4: the queries in scan order (by grid cell), (x, y, z, original index) -- one coalesced
   // 16-byte load instead of the qperm -> coordinates chain; kept in step with the caller's
   // planes here.  sp_in / sp_out: the seed of every query as a point (x, y, z, target index) in
@@ -242,7 +263,7 @@ __global__ __launch_bounds__(ICPK_GRID_BLOCK) void nn_grid_kernel(
   // the S lanes of a query are ADJACENT lanes: they read S consecutive targets (one or two
   // cache lines per query and load instruction instead of one line per lane)
   const int slice = lane & (S - 1);
-  const int wave_id = blockIdx.x * (ICPK_GRID_BLOCK / 64) + (threadIdx.x >> 6);
+  const int wave_id = block * (ICPK_GRID_BLOCK / 64) + (threadIdx.x >> 6);
   const int ip = wave_id * NQ + lane / S;
   GRID_STAMP(0);
   const bool live = ip < nq;
@@ -444,14 +465,25 @@ __global__ __launch_bounds__(ICPK_GRID_BLOCK) void nn_grid_kernel(
   GRID_STAMP(4);
 }
 
-void launch_nn_grid(const NnArgs& a, float4* qm4, const float4* t4, const int* cell_start, const GridInfo* g,
-                    const float* ox, const float* oy, const float* oz, const float4* sp_in, float4* sp_out,
-                    nn_key_t* best_m, int slices, int expand, const LoopState* st, hipStream_t s) {
-#define ICPK_LAUNCH2(SL, EX)                                                                             \
-  hipLaunchKernelGGL((nn_grid_kernel<SL, EX>),                                                           \
-                     dim3((a.nq + (ICPK_GRID_BLOCK / SL) - 1) / (ICPK_GRID_BLOCK / SL)), dim3(ICPK_GRID_BLOCK), 0, s, \
-                     const_cast<float*>(a.qx), const_cast<float*>(a.qy), const_cast<float*>(a.qz), a.nq, \
-                     qm4, t4, cell_start, g, ox, oy, oz, sp_in, sp_out, a.best, best_m, st)
+template <int S, bool EXPAND>
+__global__ __launch_bounds__(ICPK_GRID_BLOCK) void nn_grid_kernel(const GridSweepArgs a) {
+  nn_grid_body<S, EXPAND>(a, blockIdx.x);
+}
+
+// frame-batch mode: blockIdx.y = pair.  The pairs of a group differ in size: workgroups beyond
+// a pair's own count leave at once.
+template <int S, bool EXPAND>
+__global__ __launch_bounds__(ICPK_GRID_BLOCK) void nn_grid_batch_kernel(const GridSweepBatch b) {
+  const GridSweepArgs& a = b.p[blockIdx.y];
+  if ((long long)blockIdx.x * (64 / S) >= a.nq) return;
+  nn_grid_body<S, EXPAND>(a, blockIdx.x);
+}
+
+static inline int grid_blocks(int nq, int slices) { return (nq + (64 / slices) - 1) / (64 / slices); }
+
+void launch_nn_grid(const GridSweepArgs& a, int slices, int expand, hipStream_t s) {
+#define ICPK_LAUNCH2(SL, EX) \
+  hipLaunchKernelGGL((nn_grid_kernel<SL, EX>), dim3(grid_blocks(a.nq, SL)), dim3(ICPK_GRID_BLOCK), 0, s, a)
 #define ICPK_LAUNCH(SL)    \
   do {                     \
     if (expand) {          \
@@ -465,6 +497,28 @@ void launch_nn_grid(const NnArgs& a, float4* qm4, const float4* t4, const int* c
     case 2: ICPK_LAUNCH(2); break;
     case 8: ICPK_LAUNCH(8); break;
     default: ICPK_LAUNCH(4); break;
+  }
+#undef ICPK_LAUNCH
+#undef ICPK_LAUNCH2
+}
+
+void launch_nn_grid_batch(const GridSweepBatch& b, int count, int slices, int expand, hipStream_t s) {
+  int nq_max = 0;
+  for (int k = 0; k < count; ++k) nq_max = b.p[k].nq > nq_max ? b.p[k].nq : nq_max;
+  if (count <= 0 || nq_max <= 0) return;
+#define ICPK_LAUNCH2(SL, EX)                                                                            \
+  hipLaunchKernelGGL((nn_grid_batch_kernel<SL, EX>), dim3(grid_blocks(nq_max, SL), count), dim3(ICPK_GRID_BLOCK), 0, s, b)
+#define ICPK_LAUNCH(SL)    \
+  do {                     \
+    if (expand) {          \
+      ICPK_LAUNCH2(SL, true);  \
+    } else {               \
+      ICPK_LAUNCH2(SL, false); \
+    }                      \
+  } while (0)
+  switch (slices) {
+    case 4: ICPK_LAUNCH(4); break;
+    default: ICPK_LAUNCH(8); break;
   }
 #undef ICPK_LAUNCH
 #undef ICPK_LAUNCH2

@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void loop_step_kernel(const double* __restrict
   STEP_STAMP(i, 0);
   double sums[NS];
   long long npairs = 0;
-  tree_stage2<NS>(partial, pcount, nblocks, sums, npairs);
+  tree_stage2<NS, NACT>(partial, pcount, nblocks, sums, npairs);  // sums [NACT..NS) read as 0
   STEP_STAMP(i, 1);
   if (done) return;
   if (stop_after) {  // the fallback motion has been applied by the previous transform

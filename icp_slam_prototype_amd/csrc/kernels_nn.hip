@@ -16,6 +16,7 @@
 // the lexicographic min and therefore independent of scheduling order.
 #include "icpk_internal.h"
 #include "nn_device.h"
+#include "solve_impl.h"
 
 namespace icpk {
 
@@ -319,15 +320,18 @@ void launch_decimate(const float* x, const float* y, const float* z, int n, int 
 }
 
 // ---- test hook: the pair distance on its own --------------------------------
+// point3 == 0: icp.cpp:606-620 (the loop's distance); 1: icp.cpp:595-602 (cv::Point3f overload)
 __global__ void pair_distance_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
-                                     int n) {
+                                     int n, int point3) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) out[i] = pair_dist(a[i], a[n + i], a[2 * n + i], b[i], b[n + i], b[2 * n + i]);
+  if (i >= n) return;
+  out[i] = point3 ? distance3(a[i], a[n + i], a[2 * n + i], b[i], b[n + i], b[2 * n + i])
+                  : pair_dist(a[i], a[n + i], a[2 * n + i], b[i], b[n + i], b[2 * n + i]);
 }
 
-void launch_pair_distance(const float* a, const float* b, float* out, int n, hipStream_t s) {
+void launch_pair_distance(const float* a, const float* b, float* out, int n, int point3, hipStream_t s) {
   if (n <= 0) return;
-  hipLaunchKernelGGL(pair_distance_kernel, dim3((n + 255) / 256), dim3(256), 0, s, a, b, out, n);
+  hipLaunchKernelGGL(pair_distance_kernel, dim3((n + 255) / 256), dim3(256), 0, s, a, b, out, n, point3);
 }
 
 }  // namespace icpk

@@ -230,6 +230,17 @@ ICPK_HD bool solve_p2l(const double sums[28], double R[9], double t[3]) {
   return true;
 }
 
+// icp.cpp:595-602 distance(cv::Point3f, cv::Point3f): float differences, pow(float, int)
+// promotes to double, the sum and the sqrt are double, the result is narrowed on return.
+// (Not on the loop's path in the reference -- its one call site, pointcloud.cpp:246, is dead --
+// restated for SURVEY.md 8a row 7.)  The products of floats are exact in double, so the
+// explicit fma rounds like the reference's separate multiply and add.
+ICPK_HD float distance3(float ax, float ay, float az, float bx, float by, float bz) {
+  const float x = ax - bx, y = ay - by, z = az - bz;
+  const double s = ((double)x * (double)x + (double)y * (double)y) + (double)z * (double)z;
+  return (float)std::sqrt(s);
+}
+
 ICPK_HD void make_rotation_matrix(float x, float y, float z, float out[9]) {
   const float PI = 3.14159265358979f;  // icp.hpp:4
   const double rx = x * PI / 180, ry = y * PI / 180, rz = z * PI / 180;

@@ -240,8 +240,12 @@ int icpk_solve_point_to_plane(const double sums[28], double R[9], double t[3]);
  * device for n pairs; a and b are host xyz-SoA arrays [3][n].  Lets the parity
  * tests check the float/double/sqrt sequence bit for bit on its own. */
 int icpk_pair_distance(icpk_ctx *ctx, const float *a, const float *b, float *out, int32_t n);
+/* same for icp.cpp:595-602 distance(cv::Point3f, cv::Point3f): double sqrt, narrowed on
+ * return (dead in the reference: its only call site is pointcloud.cpp:246) */
+int icpk_pair_distance3(icpk_ctx *ctx, const float *a, const float *b, float *out, int32_t n);
 
 /* ---- small host helpers restated from the reference (no device work) ----- */
+float icpk_distance3(const float a[3], const float b[3]);                            /* icp.cpp:595-602      */
 void icpk_make_rotation_matrix(float x_deg, float y_deg, float z_deg, float out[9]); /* icp.cpp:640-653      */
 void icpk_matrix_to_quaternion(const float m[9], float q_wxyz[4]);                 /* quaternion.cpp:23-79 */
 void icpk_quaternion_to_euler(const float q_wxyz[4], float e_deg[3]);              /* SLAM.cpp:613-636     */

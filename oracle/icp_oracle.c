@@ -112,6 +112,60 @@ ORC_API int orc_nn_bruteforce(const float *qx, const float *qy, const float *qz,
 /* (a - b) (cv::Point3f operator- is component-wise float) over accepted     */
 /* pairs in query order, then float division by the count.                   */
 /* ------------------------------------------------------------------------ */
+/* icp.cpp:595-602 distance(cv::Point3f, cv::Point3f): x, y, z float            */
+/* differences; pow(float, int) -> double; double sum, double sqrt; the result  */
+/* is narrowed to float by the return type.  (Call site pointcloud.cpp:246 is   */
+/* dead code in the reference.)                                                 */
+/* ------------------------------------------------------------------------ */
+ORC_API float orc_distance3(float ax, float ay, float az, float bx, float by, float bz) {
+  float x = ax - bx;
+  float y = ay - by;
+  float z = az - bz;
+  return (float)sqrt(((double)x * (double)x + (double)y * (double)y) + (double)z * (double)z);
+}
+
+/* ------------------------------------------------------------------------ */
+/* icp.cpp:488-515 findGlobalKeyPointAssociations + :517-539                   */
+/* getNearestKeyPoint.  Same scan as getNearestPoint over the key-point lists; */
+/* a query is accepted when d < max_dist (MAX_NN_KEYPOINT_DISTANCE 0.1f,       */
+/* icp.hpp:10), else APPENDED to nonAssociations (:507-509; the caller's list  */
+/* is never cleared, so *n_rej is in/out); an empty map returns BEFORE         */
+/* errors/associations are cleared (:490-491): nothing is touched, return 1.   */
+/* assoc_q / assoc_t: indices of the accepted (query, nearest) pairs in query  */
+/* order; assoc_d their distances (the `errors` vector).                       */
+/* ------------------------------------------------------------------------ */
+ORC_API int orc_keypoint_associations(const float *qx, const float *qy, const float *qz, int nq,
+                                      const float *tx, const float *ty, const float *tz, int nt,
+                                      float max_dist, int32_t *assoc_q, int32_t *assoc_t,
+                                      float *assoc_d, int32_t *n_assoc, int32_t *rej_q,
+                                      int32_t *n_rej) {
+  if (nt == 0) return 1;
+  int na = 0, nr = *n_rej;
+  for (int i = 0; i < nq; i++) {
+    int best = 0;
+    float sd = orc_dist3(qx[i], qy[i], qz[i], tx[0], ty[0], tz[0]);
+    for (int j = 1; j < nt; j++) {
+      float d = orc_dist3(qx[i], qy[i], qz[i], tx[j], ty[j], tz[j]);
+      if (d < sd) {
+        sd = d;
+        best = j;
+      }
+    }
+    if (sd < max_dist) {
+      assoc_q[na] = i;
+      assoc_t[na] = best;
+      assoc_d[na] = sd;
+      na++;
+    } else {
+      rej_q[nr++] = i;
+    }
+  }
+  *n_assoc = na;
+  *n_rej = nr;
+  return 0;
+}
+
+/* ------------------------------------------------------------------------ */
 ORC_API int orc_calculate_offset_seq(const float *ax, const float *ay,
                                      const float *az, int nq, const float *tx,
                                      const float *ty, const float *tz,
@@ -627,6 +681,47 @@ ORC_API void orc_depth_range_filter(uint16_t *depth, int n, int max_d, int min_d
     else if (depth[i] < min_d)
       depth[i] = 0;
   }
+}
+
+/* SLAM.cpp:568-573: cv::getStructuringElement(MORPH_RECT, Size(5,5), Point(3,3)), then   */
+/* cv::dilate(image, image, element); cv::erode(image, image, element) on the CV_16UC1    */
+/* depth image.  OpenCV (3.2, absent here) is third-party: PARITY UNPINNED for two rules  */
+/* restated from its documentation: (1) the anchor handed to getStructuringElement only   */
+/* shapes MORPH_CROSS elements -- a MORPH_RECT element is 5x5 ones, and dilate/erode are  */
+/* called with their default anchor (-1,-1) = the element centre (2,2); the anchor is a   */
+/* parameter here so that either reading can be run; (2) the default border is            */
+/* BORDER_CONSTANT with morphologyDefaultBorderValue(): out-of-image pixels never win,    */
+/* i.e. the max (min) runs over the in-image part of the window; a window wholly outside  */
+/* (impossible with an in-range anchor) would give 0 (65535).                             */
+/* Output pixel (y, x) looks at rows y - ay .. y - ay + 4, columns x - ax .. x - ax + 4.  */
+static void orc_morph5(const uint16_t *in, uint16_t *out, int rows, int cols, int ax, int ay,
+                       int erode) {
+  for (int y = 0; y < rows; y++)
+    for (int x = 0; x < cols; x++) {
+      unsigned v = erode ? 65535u : 0u;
+      for (int ky = 0; ky < 5; ky++)
+        for (int kx = 0; kx < 5; kx++) {
+          const int yy = y - ay + ky, xx = x - ax + kx;
+          if (yy < 0 || yy >= rows || xx < 0 || xx >= cols) continue;
+          const unsigned p = in[(size_t)yy * cols + xx];
+          v = erode ? (p < v ? p : v) : (p > v ? p : v);
+        }
+      out[(size_t)y * cols + x] = (uint16_t)v;
+    }
+}
+
+/* SLAM.cpp:553-574 filterDepthImage as a whole: range clamp, 5x5 dilate, 5x5 erode. */
+ORC_API void orc_filter_depth_image(const uint16_t *in, uint16_t *out, int rows, int cols,
+                                    int max_d, int min_d, int ax, int ay) {
+  const size_t n = (size_t)rows * cols;
+  uint16_t *a = (uint16_t *)malloc(n * sizeof(uint16_t) + 2);
+  uint16_t *b = (uint16_t *)malloc(n * sizeof(uint16_t) + 2);
+  memcpy(a, in, n * sizeof(uint16_t));
+  orc_depth_range_filter(a, (int)n, max_d, min_d);
+  orc_morph5(a, b, rows, cols, ax, ay, 0);
+  orc_morph5(b, out, rows, cols, ax, ay, 1);
+  free(a);
+  free(b);
 }
 
 /* ======================================================================== */

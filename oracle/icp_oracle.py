@@ -74,6 +74,8 @@ def lib():
         assert _lib.orc_sizeof_result() == C.sizeof(Result)
         _lib.orc_distance.restype = C.c_float
         _lib.orc_distance.argtypes = [C.c_float] * 6
+        _lib.orc_distance3.restype = C.c_float
+        _lib.orc_distance3.argtypes = [C.c_float] * 6
         _lib.orc_mse_seq.restype = C.c_float
         _lib.orc_sums_canonical.restype = C.c_int64
     return _lib
@@ -95,6 +97,37 @@ def distance(a, b):
     a = np.float32(a)
     b = np.float32(b)
     return np.float32(lib().orc_distance(*[C.c_float(float(v)) for v in (*a, *b)]))
+
+
+def distance3(a, b):
+    """icp.cpp:595-602 distance(cv::Point3f, cv::Point3f)."""
+    a = np.float32(a)
+    b = np.float32(b)
+    return np.float32(lib().orc_distance3(*[C.c_float(float(v)) for v in (*a, *b)]))
+
+
+def keypoint_associations(src, tgt, max_dist=0.1, rejected=None):
+    """icp.cpp:488-539.  Returns None when the target (map key points) is empty (the
+    reference returns before touching its outputs), else (assoc_q, assoc_t, assoc_d,
+    rejected) with `rejected` = the caller's list (or []) with this sweep's rejected query
+    indices appended."""
+    sx, sy, sz = (_f(src[k]) for k in range(3))
+    tx, ty, tz = (_f(tgt[k]) for k in range(3))
+    nq, nt = sx.size, tx.size
+    prev = np.asarray([] if rejected is None else rejected, np.int32)
+    aq = np.empty(max(nq, 1), np.int32)
+    at = np.empty(max(nq, 1), np.int32)
+    ad = np.empty(max(nq, 1), np.float32)
+    rj = np.empty(prev.size + max(nq, 1), np.int32)
+    rj[:prev.size] = prev
+    na = C.c_int32(0)
+    nr = C.c_int32(prev.size)
+    rc = lib().orc_keypoint_associations(_p(sx), _p(sy), _p(sz), C.c_int(nq), _p(tx), _p(ty), _p(tz), C.c_int(nt),
+                                         C.c_float(max_dist), _p(aq, C.c_int32), _p(at, C.c_int32), _p(ad),
+                                         C.byref(na), _p(rj, C.c_int32), C.byref(nr))
+    if rc == 1:
+        return None
+    return aq[:na.value].copy(), at[:na.value].copy(), ad[:na.value].copy(), rj[:nr.value].copy()
 
 
 def nn_bruteforce(src, tgt, threads=1):
@@ -276,6 +309,15 @@ def depth_range_filter(depth, max_d=25000, min_d=1000):
     d = np.ascontiguousarray(depth, np.uint16).copy()
     lib().orc_depth_range_filter(_p(d, C.c_uint16), C.c_int(d.size), C.c_int(max_d), C.c_int(min_d))
     return d
+
+
+def filter_depth_image(depth, max_d=25000, min_d=1000, anchor=(2, 2)):
+    """SLAM.cpp:553-574 as a whole: range clamp, 5x5 dilate, 5x5 erode (anchor = (x, y))."""
+    d = np.ascontiguousarray(depth, np.uint16)
+    out = np.empty_like(d)
+    lib().orc_filter_depth_image(_p(d, C.c_uint16), _p(out, C.c_uint16), C.c_int(d.shape[0]), C.c_int(d.shape[1]),
+                                 C.c_int(max_d), C.c_int(min_d), C.c_int(anchor[0]), C.c_int(anchor[1]))
+    return out
 
 
 def align(src, tgt, max_iterations=16, threshold=1e-4, max_nn_dist=0.75, min_pairs=3,

@@ -47,6 +47,27 @@ def test_pair_distance_bits(ctx, oracle):
         assert got[i] == o or (np.isinf(got[i]) and np.isinf(o))
 
 
+def test_point3_distance_bits(ctx, oracle):
+    """icp.cpp:595-602 (double sqrt, narrowed on return) on the device, on
+    the host (icpk_distance3) and in the oracle; it differs from the loop's distance, which
+    narrows BEFORE the (float) sqrt, on a measurable share of inputs."""
+    rng = np.random.default_rng(1)
+    n = 100000
+    a = rng.uniform(-4, 4, (3, n)).astype(np.float32)
+    b = (a + rng.normal(0, 1, (3, n)) * 10.0 ** rng.uniform(-6, 1, (1, n))).astype(np.float32)
+    a[:, :10] = b[:, :10]
+    a[:, 20:30] *= np.float32(1e-18)
+    b[:, 20:30] *= np.float32(1e-18)
+    got = ctx.pair_distance(a, b, point3=True)
+    dx = (a - b).astype(np.float32).astype(np.float64)
+    want = np.sqrt((dx[0] ** 2 + dx[1] ** 2) + dx[2] ** 2).astype(np.float32)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    for i in (0, 5, 25, 100, 5000, 99999):
+        assert got[i] == oracle.distance3(a[:, i], b[:, i]) == binding.distance3(a[:, i], b[:, i])
+    loop = ctx.pair_distance(a, b)
+    assert 0 < np.count_nonzero(loop != got) < n // 4  # double rounding: the two overloads are not the same function
+
+
 # ----------------------------------------------------------------------- NN --
 def _check_nn(ctx, oracle, src, tgt):
     ctx.set_target(tgt)
@@ -404,6 +425,46 @@ def test_nn_filtered_far_apart_and_tiny_scale(ctx, oracle):
     tgt = (rng.uniform(-1, 1, (3, 4000)) * 1e-21).astype(np.float32)  # squares underflow to 0 in fp32
     src = (rng.uniform(-1, 1, (3, 500)) * 1e-21).astype(np.float32)
     _check_nn_filtered(ctx, oracle, src, tgt, moves=0)
+
+
+@pytest.mark.parametrize("scale", [1e-19, 1e-20, 1e-21, 1e-22, 1e-23])
+def test_nn_seeded_sweeps_denormal_radicands(ctx, oracle, scale):
+    """Round-1 hole: below a cloud scale of ~1e-19 the radicand
+    (float)S of icp.cpp:606-620 is a float denormal with an ABSOLUTE rounding error up to
+    2^-150, i.e. up to 2^-75 on the distance; the grid's cube slack was 2^-100.  The SEEDED
+    path (second and third sweeps, EXPAND = false) at these scales, all four kernels, 3-D and
+    1-D clouds (64-cell fallback grid), with duplicates placed either side of a cell boundary."""
+    rng = np.random.default_rng(int(-np.log10(scale)))
+    s = np.float32(scale)
+    tgt3 = (rng.uniform(-1, 1, (3, 3000)).astype(np.float32) * s).astype(np.float32)
+    src3 = (rng.uniform(-1, 1, (3, 700)).astype(np.float32) * s).astype(np.float32)
+    line = np.zeros((3, 4096), np.float32)
+    line[0] = (rng.uniform(-1, 1, 4096).astype(np.float32) * s)
+    # twins across cell boundaries of the 64-cell grid of a line: k/64 of the extent, +- 1 ulp
+    lo, hi = line[0].min(), line[0].max()
+    edges = (lo + (hi - lo) * (np.arange(1, 64, dtype=np.float32) / np.float32(64))).astype(np.float32)
+    line[0, :63] = np.nextafter(edges, np.float32(-np.inf))
+    line[0, 63:126] = np.nextafter(edges, np.float32(np.inf))
+    line[0, 126:189] = np.nextafter(edges, np.float32(-np.inf))   # duplicates of the first 63, higher index
+    qline = np.zeros((3, 3000), np.float32)
+    qline[0] = (rng.uniform(-1.2, 1.2, 3000).astype(np.float32) * s)
+    qline[0, :63] = edges
+    for src, tgt in ((src3, tgt3), (qline, line)):
+        for mode in (binding.NN_EXACT, binding.NN_FILTERED, binding.NN_PRUNED, binding.NN_GRID):
+            ctx.set_target(tgt)
+            ctx.set_source(src)
+            cur = src
+            for sweep in range(3):
+                idx, dist = ctx.nn(mode)
+                oidx, odist = oracle.nn_bruteforce(cur, tgt, threads=oracle.max_threads())
+                assert np.array_equal(idx, oidx), (mode, sweep, int(np.count_nonzero(idx != oidx)))
+                assert np.array_equal(dist.view(np.uint32), odist.view(np.uint32)), (mode, sweep)
+                if sweep == 0:
+                    continue  # second sweep: same pose, seeds = the matches themselves
+                R = oracle.make_rotation_matrix(0.02, -0.01, 0.015)  # third: after a pure small rotation
+                t = np.zeros(3, np.float32)
+                ctx.transform_source(R, t)
+                cur = oracle.transform_points(cur, R, t)
 
 
 def test_nn_filtered_kinect_quarter_frame_and_exact_agree(ctx, oracle):
