@@ -29,7 +29,7 @@ SYMBOLS = [
     "icpk_set_source_device", "icpk_reset_source", "icpk_commit_source", "icpk_get_source", "icpk_get_target", "icpk_source_size", "icpk_target_size",
     "icpk_nn", "icpk_reduce", "icpk_transform_source", "icpk_transform_target", "icpk_get_trace",
     "icpk_get_associations", "icpk_align",
-    "icpk_align_batch", "icpk_backproject", "icpk_backproject_with_normals", "icpk_set_target_normals",
+    "icpk_align_batch", "icpk_align_batch_device", "icpk_backproject", "icpk_backproject_with_normals", "icpk_set_target_normals",
     "icpk_get_target_normals", "icpk_reduce_p2l", "icpk_solve_point_to_plane", "icpk_pair_distance", "icpk_pair_distance3", "icpk_distance3", "icpk_make_rotation_matrix",
     "icpk_matrix_to_quaternion", "icpk_quaternion_to_euler", "icpk_solve_reference", "icpk_solve_kabsch",
 ]
@@ -73,6 +73,7 @@ class Pair(C.Structure):
         ("ns", C.c_int32),
         ("tx", C.POINTER(C.c_float)), ("ty", C.POINTER(C.c_float)), ("tz", C.POINTER(C.c_float)),
         ("nt", C.c_int32),
+        ("idx_out", C.POINTER(C.c_int32)), ("dist_out", C.POINTER(C.c_float)),
     ]
 
 
@@ -123,6 +124,7 @@ def load():
     lib.icpk_get_associations.argtypes = [C.c_void_p, C.POINTER(C.c_int32), fp]
     lib.icpk_align.argtypes = [C.c_void_p, C.POINTER(Params), fp, C.POINTER(Stats)]
     lib.icpk_align_batch.argtypes = [C.c_void_p, C.c_int32, C.POINTER(Pair), C.POINTER(Params), fp, C.POINTER(Stats)]
+    lib.icpk_align_batch_device.argtypes = lib.icpk_align_batch.argtypes
     lib.icpk_backproject.argtypes = [C.c_void_p, C.POINTER(C.c_uint16), C.c_int32, C.c_int32, C.c_float, C.c_float,
                                      fp, C.c_int32]
     lib.icpk_pair_distance.argtypes = [C.c_void_p, fp, fp, fp, C.c_int32]
@@ -404,21 +406,46 @@ class Context:
         rc = self._chk(self._lib.icpk_align(self._h, C.byref(p), _fp(T), C.byref(st)))
         return T.reshape(4, 4), st, rc
 
-    def align_batch(self, pairs, params=None, **kw):
-        """pairs: list of (source (3,Ns), target (3,Nt)) host arrays."""
+    def align_batch(self, pairs, params=None, associations=False, **kw):
+        """pairs: list of (source (3,Ns), target (3,Nt)) host arrays.  Returns (T (n,4,4), stats list,
+        rc) and, with associations=True, additionally a list of (idx, dist) per pair."""
         p = params if params is not None else default_params(**kw)
         n = len(pairs)
         arr = (Pair * max(n, 1))()
         keep = []
+        assoc = []
         for b, (s, t) in enumerate(pairs):
             sx, sy, sz = (_f(s[k]) for k in range(3))
             tx, ty, tz = (_f(t[k]) for k in range(3))
             keep.append((sx, sy, sz, tx, ty, tz))
             arr[b].sx, arr[b].sy, arr[b].sz, arr[b].ns = _fp(sx), _fp(sy), _fp(sz), sx.size
             arr[b].tx, arr[b].ty, arr[b].tz, arr[b].nt = _fp(tx), _fp(ty), _fp(tz), tx.size
+            if associations:
+                idx = np.full(sx.size, -1, np.int32)
+                dist = np.full(sx.size, np.nan, np.float32)
+                assoc.append((idx, dist))
+                arr[b].idx_out = idx.ctypes.data_as(C.POINTER(C.c_int32))
+                arr[b].dist_out = _fp(dist)
         T = np.zeros((max(n, 1), 16), np.float32)
         st = (Stats * max(n, 1))()
         rc = self._lib.icpk_align_batch(self._h, n, arr, C.byref(p), _fp(T), st)
+        out = (T[:n].reshape(n, 4, 4), list(st)[:n], rc)
+        return out + (assoc,) if associations else out
+
+    def align_batch_device(self, pairs, params=None, **kw):
+        """pairs: list of (src_ptr, ns, tgt_ptr, nt): device addresses of (3, N) float32 xyz-SoA
+        blocks (plane stride = N floats) resident on this context's device."""
+        p = params if params is not None else default_params(**kw)
+        n = len(pairs)
+        arr = (Pair * max(n, 1))()
+        fpt = C.POINTER(C.c_float)
+        for b, (sp, ns, tp, nt) in enumerate(pairs):
+            arr[b].sx, arr[b].sy, arr[b].sz = (C.cast(C.c_void_p(sp + 4 * ns * k), fpt) for k in range(3))
+            arr[b].tx, arr[b].ty, arr[b].tz = (C.cast(C.c_void_p(tp + 4 * nt * k), fpt) for k in range(3))
+            arr[b].ns, arr[b].nt = ns, nt
+        T = np.zeros((max(n, 1), 16), np.float32)
+        st = (Stats * max(n, 1))()
+        rc = self._lib.icpk_align_batch_device(self._h, n, arr, C.byref(p), _fp(T), st)
         return T[:n].reshape(n, 4, 4), list(st)[:n], rc
 
     def set_log_callback(self, fn):

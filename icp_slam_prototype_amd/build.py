@@ -10,7 +10,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libicpk.so")
 
-SOURCES = ["icpk_api.cpp", "solve.cpp", "kernels_nn.hip", "kernels_reduce.hip", "kernels_transform.hip",
+SOURCES = ["icpk_api.cpp", "kernels_nn.hip", "kernels_reduce.hip", "kernels_transform.hip",
            "kernels_backproject.hip", "kernels_sort.hip", "kernels_nn_pruned.hip", "kernels_loop.hip", "kernels_grid.hip"]
 
 # -ffp-contract=off: the exact kernels spell out every fma they want; nothing may

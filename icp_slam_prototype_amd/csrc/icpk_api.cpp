@@ -100,6 +100,15 @@ struct icpk_ctx {
   float4* sp_out = nullptr;  // ... written by it
   int qm4_cap = 0;
   GridInfo grid_host{};      // host copy of *grid_info (read back once per target)
+  GridInfo* grid_host_pin = nullptr;  // pinned landing buffer of that read-back (truly asynchronous copy)
+  bool grid_phase1 = false;  // bounds / info of the current target are enqueued, read-back in flight
+  // frame-batch mode: child contexts (one per pair in flight; own stream for set-up work) --
+  // owned by the parent, never handed out
+  std::vector<icpk_ctx*> slots;
+  hipEvent_t ready_ev = nullptr;       // slot: set-up of the current pair is enqueued up to here
+  hipEvent_t group_ev[2] = {nullptr, nullptr};  // parent: the lock-step loop of a slot set has finished
+  int batch_group = 8;                 // pairs advancing in lock step (ICPK_BATCH_GROUP, <= BATCH_MAX)
+  std::vector<nn_key_t*> best_of_sweep;  // device loop: which buffer each enqueued sweep wrote
   int* qcount = nullptr;     // query counting sort by cell: counts and starts, GRID_MAX_CELLS + 1 each
   int* qstart = nullptr;
   void* scan_temp = nullptr;
@@ -177,7 +186,7 @@ int ensure_assoc(icpk_ctx* ctx, int nq) {
 // pad value: +inf for targets (a padded target is never nearer than a real
 // one), 0 for sources (padded queries are computed and discarded)
 int upload_cloud(icpk_ctx* ctx, Cloud& c, const float* x, const float* y, const float* z, int n, float pad,
-                 hipMemcpyKind kind) {
+                 hipMemcpyKind kind, bool sync = true) {
   if (n < 0 || (n > 0 && (!x || !y || !z))) return fail(ctx, ICPK_E_ARG, "bad cloud pointers/size");
   int rc = ensure_cloud(ctx, c, n);
   if (rc) return rc;
@@ -190,8 +199,9 @@ int upload_cloud(icpk_ctx* ctx, Cloud& c, const float* x, const float* y, const 
   launch_fill_f32(c.y() + n, c.cap - n, pad, ctx->stream);
   launch_fill_f32(c.z() + n, c.cap - n, pad, ctx->stream);
   ICPK_HIP(ctx, hipGetLastError());
-  // host buffers are only valid for the duration of the call
-  ICPK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  // host buffers are only valid for the duration of the call (the frame-batch entry points
+  // keep theirs alive until they return and synchronise once at the end)
+  if (sync) ICPK_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return ICPK_OK;
 }
 
@@ -338,9 +348,13 @@ int ensure_scan_buffers(icpk_ctx* ctx, int n) {
   return ICPK_OK;
 }
 
-int prepare_grid_target(icpk_ctx* ctx) {
+// phase 1: bounds and cell size of the current target, read-back of the 36-byte GridInfo enqueued
+// (the host needs the grid's size to dimension the counting sorts)
+int grid_target_phase1(icpk_ctx* ctx) {
   const int nt = ctx->tgt.n;
   if (!ctx->grid_info) ICPK_HIP(ctx, hipMalloc((void**)&ctx->grid_info, sizeof(GridInfo)));
+  if (!ctx->grid_host_pin)
+    ICPK_HIP(ctx, hipHostMalloc((void**)&ctx->grid_host_pin, sizeof(GridInfo), hipHostMallocDefault));
   if (!ctx->grid_bounds)
     ICPK_HIP(ctx, hipMalloc((void**)&ctx->grid_bounds, (size_t)GRID_BOUNDS_PARTS * 6 * sizeof(float)));
   if (!ctx->cell_start) ICPK_HIP(ctx, hipMalloc((void**)&ctx->cell_start, ((size_t)GRID_MAX_CELLS + 1) * sizeof(int)));
@@ -352,15 +366,26 @@ int prepare_grid_target(icpk_ctx* ctx) {
     ctx->t4_cap = round_up(nt, NN_TILE);
     ctx->have_grid = false;
   }
-  if (ctx->have_grid) return ICPK_OK;
+  if (ctx->have_grid || ctx->grid_phase1) return ICPK_OK;
   int rc = ensure_sort_buffers(ctx, nt);
   if (rc) return rc;
   launch_grid_bounds(ctx->tgt.x(), ctx->tgt.y(), ctx->tgt.z(), nt, ctx->grid_bounds, ctx->stream);
   launch_grid_info(ctx->grid_bounds, nt, ctx->grid_ppc, ctx->grid_info, ctx->stream);
-  // the host needs the grid's size to dimension the counting sorts (set-up path: one 36-byte
-  // read-back and a stream sync per target cloud)
-  ICPK_HIP(ctx, hipMemcpyAsync(&ctx->grid_host, ctx->grid_info, sizeof(GridInfo), hipMemcpyDeviceToHost, ctx->stream));
+  ICPK_HIP(ctx, hipMemcpyAsync(ctx->grid_host_pin, ctx->grid_info, sizeof(GridInfo), hipMemcpyDeviceToHost, ctx->stream));
+  ctx->grid_phase1 = true;
+  return ICPK_OK;
+}
+
+// cell table + cell-sorted AoS copy of the target for the grid scan (once per target cloud)
+int prepare_grid_target(icpk_ctx* ctx) {
+  const int nt = ctx->tgt.n;
+  int rc = grid_target_phase1(ctx);
+  if (rc) return rc;
+  if (ctx->have_grid) return ICPK_OK;
+  // set-up path: one stream sync per target cloud
   ICPK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->grid_phase1 = false;
+  ctx->grid_host = *ctx->grid_host_pin;
   const int ncells = ctx->grid_host.ncells;
   if (ncells < 1 || ncells > GRID_MAX_CELLS) return fail(ctx, ICPK_E_HIP, "grid info not available");
   rc = ensure_scan_buffers(ctx, ncells + 1);
@@ -404,6 +429,144 @@ int enqueue_cell_order(icpk_ctx* ctx) {
   return ICPK_OK;
 }
 
+// Everything a pruned / grid sweep needs before its K1 launch: query order (once per alignment),
+// seeds in scan order, buffer rotation.  Enqueues on ctx->stream only for the FIRST sweep of a
+// chain; for a sweep that continues a chain of grid sweeps inside a device loop it merely
+// rotates pointers.  recheck = 1: the seeds are loose (first sweep).
+int prepare_sorted_sweep(icpk_ctx* ctx, int nn_mode, NnArgs& a, NnBoxes& bx, int& recheck) {
+  const int nq = ctx->src.n;
+  int rc = ICPK_OK;
+  if (round_up(nq, NN_TILE) > ctx->qperm_cap) {
+    if (ctx->qperm) ICPK_HIP(ctx, hipFree(ctx->qperm));
+    ctx->qperm = nullptr;
+    ctx->qperm_cap = 0;
+    ICPK_HIP(ctx, hipMalloc((void**)&ctx->qperm, (size_t)round_up(nq, NN_TILE) * sizeof(int)));
+    ctx->qperm_cap = round_up(nq, NN_TILE);
+    ctx->have_qperm = false;
+  }
+  bx = NnBoxes{};
+  if (nn_mode == ICPK_NN_GRID) {
+    bx.ox = ctx->tgt.x();
+    bx.oy = ctx->tgt.y();
+    bx.oz = ctx->tgt.z();
+    rc = prepare_grid_target(ctx);
+  } else {
+    rc = prepare_pruned_target(ctx, bx);
+  }
+  if (rc) return rc;
+  bool new_order = false;
+  const int want_kind = nn_mode == ICPK_NN_GRID ? 2 : 1;
+  if (!ctx->have_qperm || !ctx->have_seed || ctx->qperm_kind != want_kind) {
+    // query order (once per alignment), from the source at its current pose: Morton order
+    // for the pruned scan (the unsorted Morton keys of the queries stay in sort_keys[0..nq)
+    // for its first-sweep seeds), order by grid cell (a cheaper counting sort) for the grid scan
+    if (nn_mode == ICPK_NN_GRID) {
+      rc = enqueue_cell_order(ctx);
+    } else {
+      rc = enqueue_morton_order(ctx, ctx->src, ctx->qperm);
+    }
+    if (rc) return rc;
+    ctx->have_qperm = true;
+    ctx->qperm_kind = want_kind;
+    new_order = true;
+  }
+  recheck = 0;
+  if (ctx->have_seed && ctx->have_seed_m && !new_order) {
+    // matches of the previous pruned sweep, already in query Morton order
+    std::swap(ctx->seed_m, ctx->best_m);
+    std::swap(ctx->seed, ctx->best);
+  } else if (ctx->have_seed) {  // matches of a sweep by another kernel: bring them into Morton order
+    launch_seed_gather(ctx->best, ctx->qperm, nq, ctx->seed_m, ctx->stream);
+    std::swap(ctx->seed, ctx->best);
+  } else if (nn_mode == ICPK_NN_GRID) {
+    // first sweep of the grid scan: the reference's own literal seed, element 0 (icp.cpp:572);
+    // the expanding search does not depend on the seed's quality
+    launch_fill_u64(ctx->seed_m, nq, 0ull, nullptr, ctx->stream);
+    recheck = 1;
+  } else {  // first sweep: the target with the nearest Morton code; loose, so re-check lazily
+    launch_seed_morton(ctx->sort_keys, ctx->qperm, nq, ctx->src.x(), ctx->src.y(), ctx->src.z(), ctx->tkeys,
+                       ctx->sorted.x(), ctx->sorted.y(), ctx->sorted.z(), ctx->tperm, ctx->tgt.n, ctx->seed_m,
+                       ctx->stream);
+    recheck = 1;
+  }
+  a.tx = ctx->sorted.x();
+  a.ty = ctx->sorted.y();
+  a.tz = ctx->sorted.z();
+  a.tiles_per_chunk = a.nt_pad / NN_TILE;
+  a.best = ctx->best;
+  if (nn_mode == ICPK_NN_GRID) {
+    if (nq > ctx->qm4_cap) {
+      for (float4** pp : {&ctx->qm4, &ctx->sp_in, &ctx->sp_out}) {
+        if (*pp) ICPK_HIP(ctx, hipFree(*pp));
+        *pp = nullptr;
+      }
+      ctx->qm4_cap = 0;
+      const size_t bytes = ((size_t)round_up(nq, NN_TILE) + 64) * sizeof(float4);
+      ICPK_HIP(ctx, hipMalloc((void**)&ctx->qm4, bytes));
+      ICPK_HIP(ctx, hipMalloc((void**)&ctx->sp_in, bytes));
+      ICPK_HIP(ctx, hipMalloc((void**)&ctx->sp_out, bytes));
+      ctx->qm4_cap = round_up(nq, NN_TILE);
+      ctx->grid_chain = false;
+    }
+    // inside a device loop the grid sweeps keep qm4 / the seed points current themselves;
+    // anywhere else the source may have been moved by other kernels: gather afresh
+    if (!(ctx->st_active && ctx->grid_chain))
+      launch_grid_query_points(ctx->src.x(), ctx->src.y(), ctx->src.z(), ctx->qperm, nq, ctx->seed_m, bx.ox, bx.oy,
+                               bx.oz, ctx->qm4, ctx->sp_in, ctx->stream);
+  }
+  ICPK_HIP(ctx, hipGetLastError());
+  return ICPK_OK;
+}
+
+// lanes per query of the grid scan (measured: 8 is best from 10k to 307k queries, 4 at 10^6)
+int grid_slices_for(const icpk_ctx* ctx, int nq) { return ctx->grid_slices ? ctx->grid_slices : (nq > 500000 ? 4 : 8); }
+
+// the K1d arguments of the sweep prepare_sorted_sweep has just set up, and the bookkeeping
+// that follows its launch
+GridSweepArgs grid_sweep_args(icpk_ctx* ctx, const NnArgs& a, const NnBoxes& bx) {
+  GridSweepArgs g{};
+  g.qx = const_cast<float*>(a.qx);
+  g.qy = const_cast<float*>(a.qy);
+  g.qz = const_cast<float*>(a.qz);
+  g.nq = a.nq;
+  g.qm4 = ctx->qm4;
+  g.t4 = ctx->t4;
+  g.cell_start = ctx->cell_start;
+  g.gi = ctx->grid_info;
+  g.ox = bx.ox;
+  g.oy = bx.oy;
+  g.oz = bx.oz;
+  g.sp_in = ctx->sp_in;
+  g.sp_out = ctx->sp_out;
+  g.best = a.best;
+  g.best_m = ctx->best_m;
+  g.st = ctx->st_active;
+  return g;
+}
+void after_grid_sweep(icpk_ctx* ctx) {
+  std::swap(ctx->sp_in, ctx->sp_out);
+  ctx->grid_chain = ctx->st_active != nullptr;
+  ctx->have_assoc = true;
+  ctx->have_seed = true;
+  ctx->have_seed_m = true;
+}
+
+NnArgs base_nn_args(const icpk_ctx* ctx) {
+  NnArgs a;
+  a.qx = ctx->src.x();
+  a.qy = ctx->src.y();
+  a.qz = ctx->src.z();
+  a.nq = ctx->src.n;
+  a.tx = ctx->tgt.x();
+  a.ty = ctx->tgt.y();
+  a.tz = ctx->tgt.z();
+  a.nt_pad = round_up(ctx->tgt.n, NN_TILE);
+  a.tiles_per_chunk = a.nt_pad / NN_TILE;
+  a.best = ctx->best;
+  a.stop = ctx->stop;
+  return a;
+}
+
 // enqueue one NN sweep (K1) over the working source; ev0/ev1 (optional) are recorded
 // immediately before/after the K1 launch itself, so that set-up kernels of a first sweep
 // (sort, seeding, fills) do not count as kernel time
@@ -427,16 +590,7 @@ int enqueue_nn(icpk_ctx* ctx, int nn_mode, hipEvent_t ev0 = nullptr, hipEvent_t 
     if (nchunks > ntiles) nchunks = ntiles;
     return (ntiles + nchunks - 1) / nchunks;
   };
-  NnArgs a;
-  a.qx = ctx->src.x();
-  a.qy = ctx->src.y();
-  a.qz = ctx->src.z();
-  a.nq = nq;
-  a.tx = ctx->tgt.x();
-  a.ty = ctx->tgt.y();
-  a.tz = ctx->tgt.z();
-  a.nt_pad = round_up(ctx->tgt.n, NN_TILE);
-  a.stop = ctx->stop;
+  NnArgs a = base_nn_args(ctx);
   const int ntiles = a.nt_pad / NN_TILE;
   if (nn_mode == ICPK_NN_EXACT) {
     a.tiles_per_chunk = chunking((nq + NN_THREADS - 1) / NN_THREADS, ntiles);
@@ -446,122 +600,36 @@ int enqueue_nn(icpk_ctx* ctx, int nn_mode, hipEvent_t ev0 = nullptr, hipEvent_t 
     launch_nn_exact(a, ctx->stream);
     if ((rc = mark(ev1))) return rc;
   } else if (nn_mode == ICPK_NN_PRUNED || nn_mode == ICPK_NN_GRID) {
-    if (round_up(nq, NN_TILE) > ctx->qperm_cap) {
-      if (ctx->qperm) ICPK_HIP(ctx, hipFree(ctx->qperm));
-      ctx->qperm = nullptr;
-      ctx->qperm_cap = 0;
-      ICPK_HIP(ctx, hipMalloc((void**)&ctx->qperm, (size_t)round_up(nq, NN_TILE) * sizeof(int)));
-      ctx->qperm_cap = round_up(nq, NN_TILE);
-      ctx->have_qperm = false;
-    }
     NnBoxes bx{};
-    if (nn_mode == ICPK_NN_GRID) {
-      bx.ox = ctx->tgt.x();
-      bx.oy = ctx->tgt.y();
-      bx.oz = ctx->tgt.z();
-      rc = prepare_grid_target(ctx);
-    } else {
-      rc = prepare_pruned_target(ctx, bx);
-    }
-    if (rc) return rc;
-    bool new_order = false;
-    const int want_kind = nn_mode == ICPK_NN_GRID ? 2 : 1;
-    if (!ctx->have_qperm || !ctx->have_seed || ctx->qperm_kind != want_kind) {
-      // query order (once per alignment), from the source at its current pose: Morton order
-      // for the pruned scan (the unsorted Morton keys of the queries stay in sort_keys[0..nq)
-      // for its first-sweep seeds), order by grid cell (a cheaper counting sort) for the grid scan
-      if (nn_mode == ICPK_NN_GRID) {
-        rc = enqueue_cell_order(ctx);
-      } else {
-        rc = enqueue_morton_order(ctx, ctx->src, ctx->qperm);
-      }
-      if (rc) return rc;
-      ctx->have_qperm = true;
-      ctx->qperm_kind = want_kind;
-      new_order = true;
-    }
     int recheck = 0;
-    if (ctx->have_seed && ctx->have_seed_m && !new_order) {
-      // matches of the previous pruned sweep, already in query Morton order
-      nn_key_t* t = ctx->seed_m;
-      ctx->seed_m = ctx->best_m;
-      ctx->best_m = t;
-      t = ctx->seed;
-      ctx->seed = ctx->best;
-      ctx->best = t;
-    } else if (ctx->have_seed) {  // matches of a sweep by another kernel: bring them into Morton order
-      launch_seed_gather(ctx->best, ctx->qperm, nq, ctx->seed_m, ctx->stream);
-      nn_key_t* t = ctx->seed;
-      ctx->seed = ctx->best;
-      ctx->best = t;
-    } else if (nn_mode == ICPK_NN_GRID) {
-      // first sweep of the grid scan: the reference's own literal seed, element 0 (icp.cpp:572);
-      // the expanding search does not depend on the seed's quality
-      launch_fill_u64(ctx->seed_m, nq, 0ull, nullptr, ctx->stream);
-      recheck = 1;
-    } else {  // first sweep: the target with the nearest Morton code; loose, so re-check lazily
-      launch_seed_morton(ctx->sort_keys, ctx->qperm, nq, ctx->src.x(), ctx->src.y(), ctx->src.z(), ctx->tkeys,
-                         ctx->sorted.x(), ctx->sorted.y(), ctx->sorted.z(), ctx->tperm, ctx->tgt.n, ctx->seed_m,
-                         ctx->stream);
-      recheck = 1;
-    }
-    a.tx = ctx->sorted.x();
-    a.ty = ctx->sorted.y();
-    a.tz = ctx->sorted.z();
-    a.tiles_per_chunk = ntiles;
-    a.best = ctx->best;
-    if (nn_mode == ICPK_NN_GRID) {
-      if (nq > ctx->qm4_cap) {
-        for (float4** pp : {&ctx->qm4, &ctx->sp_in, &ctx->sp_out}) {
-          if (*pp) ICPK_HIP(ctx, hipFree(*pp));
-          *pp = nullptr;
-        }
-        ctx->qm4_cap = 0;
-        const size_t bytes = ((size_t)round_up(nq, NN_TILE) + 64) * sizeof(float4);
-        ICPK_HIP(ctx, hipMalloc((void**)&ctx->qm4, bytes));
-        ICPK_HIP(ctx, hipMalloc((void**)&ctx->sp_in, bytes));
-        ICPK_HIP(ctx, hipMalloc((void**)&ctx->sp_out, bytes));
-        ctx->qm4_cap = round_up(nq, NN_TILE);
-        ctx->grid_chain = false;
-      }
-      // inside a device loop the grid sweeps keep qm4 / the seed points current themselves;
-      // anywhere else the source may have been moved by other kernels: gather afresh
-      if (!(ctx->st_active && ctx->grid_chain))
-        launch_grid_query_points(ctx->src.x(), ctx->src.y(), ctx->src.z(), ctx->qperm, nq, ctx->seed_m, bx.ox, bx.oy,
-                                 bx.oz, ctx->qm4, ctx->sp_in, ctx->stream);
-    }
+    rc = prepare_sorted_sweep(ctx, nn_mode, a, bx, recheck);
+    if (rc) return rc;
     if ((rc = mark(ev0))) return rc;
-    // lanes per query: as many as keep the launch at <= ~10k waves (measured best: 16 at 10k
-    // queries, 4 at 92k, 2 at 217k-307k, 1 at 10^6)
-    int slices = ctx->slices;
-    if (slices == 0) {
-      slices = 16;
-      while (slices > 1 && (long long)nq * slices / 64 > 10000) slices >>= 1;
-    }
     if (nn_mode == ICPK_NN_GRID) {
-      int gs = ctx->grid_slices;
-      if (gs == 0) gs = nq > 500000 ? 4 : 8;  // measured: 8 is best from 10k to 307k queries, 4 at 10^6
-      launch_nn_grid(a, ctx->qm4, ctx->t4, ctx->cell_start, ctx->grid_info, bx.ox, bx.oy, bx.oz, ctx->sp_in,
-                     ctx->sp_out, ctx->best_m, gs, recheck, ctx->st_active, ctx->stream);
-      std::swap(ctx->sp_in, ctx->sp_out);
-      ctx->grid_chain = ctx->st_active != nullptr;
+      launch_nn_grid(grid_sweep_args(ctx, a, bx), grid_slices_for(ctx, nq), recheck, ctx->stream);
+      after_grid_sweep(ctx);
     } else {
+      // lanes per query: as many as keep the launch at <= ~10k waves (measured best: 16 at 10k
+      // queries, 4 at 92k, 2 at 217k-307k, 1 at 10^6)
+      int slices = ctx->slices;
+      if (slices == 0) {
+        slices = 16;
+        while (slices > 1 && (long long)nq * slices / 64 > 10000) slices >>= 1;
+      }
       launch_nn_pruned(a, ctx->seed_m, ctx->best_m, bx, slices, recheck, ctx->st_active, ctx->stream);
       ctx->grid_chain = false;
+      ctx->have_assoc = true;
+      ctx->have_seed = true;
+      ctx->have_seed_m = true;
     }
     if ((rc = mark(ev1))) return rc;
     ICPK_HIP(ctx, hipGetLastError());
-    ctx->have_assoc = true;
-    ctx->have_seed = true;
-    ctx->have_seed_m = true;
     return ICPK_OK;
   } else {
     int seed_scale = 1;
     if (ctx->have_seed) {
       // matches of the previous sweep (same clouds, source possibly moved) seed this one
-      nn_key_t* t = ctx->seed;
-      ctx->seed = ctx->best;
-      ctx->best = t;
+      std::swap(ctx->seed, ctx->best);
     } else {
       // coarse pre-pass: exact NN against every NN_SEED_STRIDE-th target
       if (!ctx->have_dec) {
@@ -650,13 +718,9 @@ void icpk_default_params(icpk_params* p) {
   p->last_rotation[0] = p->last_rotation[4] = p->last_rotation[8] = 1.f;
 }
 
-int icpk_create(icpk_ctx** out, int device_id) {
-  if (!out) return ICPK_E_ARG;
-  *out = nullptr;
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return ICPK_E_NO_DEVICE;
-  if (device_id < 0 || device_id >= ndev) return ICPK_E_NO_DEVICE;
-  if (hipSetDevice(device_id) != hipSuccess) return ICPK_E_NO_DEVICE;
+// stream + the fixed-size buffers every context owns; `parent` != nullptr: a frame-batch slot
+// (inherits the tuning knobs)
+static icpk_ctx* make_context(int device_id, const icpk_ctx* parent) {
   icpk_ctx* ctx = new icpk_ctx();
   ctx->device = device_id;
   bool ok = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess;
@@ -667,10 +731,33 @@ int icpk_create(icpk_ctx** out, int device_id) {
   ok = ok && hipHostMalloc((void**)&ctx->bp_n_host, sizeof(int), hipHostMallocDefault) == hipSuccess;
   ok = ok && hipMalloc((void**)&ctx->st_dev, sizeof(LoopState)) == hipSuccess;
   ok = ok && hipHostMalloc((void**)&ctx->st_host, sizeof(LoopState), hipHostMallocDefault) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&ctx->ready_ev, hipEventDisableTiming) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&ctx->group_ev[0], hipEventDisableTiming) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&ctx->group_ev[1], hipEventDisableTiming) == hipSuccess;
   if (!ok) {
     icpk_destroy(ctx);
-    return ICPK_E_HIP;
+    return nullptr;
   }
+  if (parent) {
+    ctx->target_blocks = parent->target_blocks;
+    ctx->slices = parent->slices;
+    ctx->grid_ppc = parent->grid_ppc;
+    ctx->grid_slices = parent->grid_slices;
+    ctx->q_per_lane = parent->q_per_lane;
+  }
+  ctx->log_last = std::chrono::steady_clock::now();
+  return ctx;
+}
+
+int icpk_create(icpk_ctx** out, int device_id) {
+  if (!out) return ICPK_E_ARG;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return ICPK_E_NO_DEVICE;
+  if (device_id < 0 || device_id >= ndev) return ICPK_E_NO_DEVICE;
+  if (hipSetDevice(device_id) != hipSuccess) return ICPK_E_NO_DEVICE;
+  icpk_ctx* ctx = make_context(device_id, nullptr);
+  if (!ctx) return ICPK_E_HIP;
   if (const char* e = std::getenv("ICPK_NN_TARGET_BLOCKS")) {
     const int v = std::atoi(e);
     if (v > 0) ctx->target_blocks = v;
@@ -691,7 +778,10 @@ int icpk_create(icpk_ctx** out, int device_id) {
     const int v = std::atoi(e);
     if (v == 1 || v == 2) ctx->q_per_lane = v;
   }
-  ctx->log_last = std::chrono::steady_clock::now();
+  if (const char* e = std::getenv("ICPK_BATCH_GROUP")) {
+    const int v = std::atoi(e);
+    if (v >= 1 && v <= BATCH_MAX) ctx->batch_group = v;
+  }
   *out = ctx;
   return ICPK_OK;
 }
@@ -700,6 +790,11 @@ void icpk_destroy(icpk_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  for (icpk_ctx* sl : ctx->slots) icpk_destroy(sl);
+  ctx->slots.clear();
+  for (hipEvent_t e : {ctx->ready_ev, ctx->group_ev[0], ctx->group_ev[1]})
+    if (e) (void)hipEventDestroy(e);
+  if (ctx->grid_host_pin) (void)hipHostFree(ctx->grid_host_pin);
   for (hipEvent_t e : ctx->events) (void)hipEventDestroy(e);
   void* dev[] = {ctx->qcount, ctx->qstart, ctx->scan_temp, ctx->qm4, ctx->sp_in, ctx->sp_out, ctx->grid_info, ctx->grid_bounds, ctx->cell_start, ctx->t4, ctx->best_m, ctx->seed_m, ctx->st_dev, ctx->sorted.base, ctx->tkeys, ctx->tperm, ctx->qperm, ctx->bounds, ctx->sort_keys, ctx->sort_vals, ctx->sort_temp,
                  ctx->nrm.base, ctx->boxes, ctx->dec.base, ctx->tgt.base, ctx->src0.base, ctx->src.base, ctx->best,      ctx->seed,     ctx->idx,
@@ -725,26 +820,28 @@ int icpk_set_log_callback(icpk_ctx* ctx, icpk_log_fn fn, void* user) {
 
 void* icpk_stream(icpk_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 
-static int set_target_impl(icpk_ctx* ctx, const float* x, const float* y, const float* z, int32_t n, hipMemcpyKind k) {
+static int set_target_impl(icpk_ctx* ctx, const float* x, const float* y, const float* z, int32_t n, hipMemcpyKind k,
+                           bool sync = true) {
   if (!ctx) return ICPK_E_ARG;
   ICPK_HIP(ctx, hipSetDevice(ctx->device));
-  int rc = upload_cloud(ctx, ctx->tgt, x, y, z, n, __builtin_inff(), k);
+  int rc = upload_cloud(ctx, ctx->tgt, x, y, z, n, __builtin_inff(), k, sync);
   if (rc) return rc;
   ctx->have_tgt = true;
   ctx->have_assoc = false;
   ctx->have_dec = false;
   ctx->have_boxes = false;
   ctx->have_grid = false;
-  ctx->have_grid = false;
+  ctx->grid_phase1 = false;
   ctx->have_seed = false;
   ctx->have_normals = false;
   return ICPK_OK;
 }
 
-static int set_source_impl(icpk_ctx* ctx, const float* x, const float* y, const float* z, int32_t n, hipMemcpyKind k) {
+static int set_source_impl(icpk_ctx* ctx, const float* x, const float* y, const float* z, int32_t n, hipMemcpyKind k,
+                           bool sync = true) {
   if (!ctx) return ICPK_E_ARG;
   ICPK_HIP(ctx, hipSetDevice(ctx->device));
-  int rc = upload_cloud(ctx, ctx->src0, x, y, z, n, 0.f, k);
+  int rc = upload_cloud(ctx, ctx->src0, x, y, z, n, 0.f, k, sync);
   if (rc) return rc;
   ctx->have_src = true;
   ctx->have_assoc = false;
@@ -752,7 +849,7 @@ static int set_source_impl(icpk_ctx* ctx, const float* x, const float* y, const 
   ctx->have_qperm = false;
   rc = copy_src0_to_src(ctx);
   if (rc) return rc;
-  ICPK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (sync) ICPK_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return ICPK_OK;
 }
 
@@ -886,28 +983,14 @@ int icpk_transform_source(icpk_ctx* ctx, const float R[9], const float t[3]) {
   return ICPK_OK;
 }
 
-// Whole alignment enqueued up front; loop test, solve and pose accumulation run on the
-// device (kernels_loop.hip).  Same results as the host loop below.
-static int align_device_loop(icpk_ctx* ctx, const icpk_params* p, float T_out[16], icpk_stats* stats) {
-  const bool prof = p->profile != 0;
-  const bool prof_all = p->profile >= 2;  // 1: NN kernels only (2 events per sweep); 2: every stage
-  const bool p2l = p->solve == ICPK_SOLVE_POINT_TO_PLANE;
-  const bool fused = p->nn_mode == ICPK_NN_PRUNED || p->nn_mode == ICPK_NN_GRID;  // K3 runs inside the sweep
-  // the reference flavour's step reads sums [0..12] only: K2 and stage 2 skip the rest
-  const int nsum = p2l ? NP2L : (p->solve == ICPK_SOLVE_REFERENCE ? NSUM_REF : NSUM);
-  ctx->loop_nact = nsum == NSUM_REF ? NSUM_REF : NSUM;
-  const int B = red_blocks(ctx->src.n);
-  size_t nev = 0;
-  std::vector<size_t> ev_nn, ev_red, ev_tr;
-  auto stamp = [&](std::vector<size_t>* list) -> int {
-    if (!prof) return ICPK_OK;
-    hipEvent_t e = get_event(ctx, nev);
-    if (!e) return fail(ctx, ICPK_E_HIP, "hipEventCreate failed");
-    ICPK_HIP(ctx, hipEventRecord(e, ctx->stream));
-    if (list) list->push_back(nev);
-    ++nev;
-    return ICPK_OK;
-  };
+// ---- device-side loop: begin / finish, shared by the single-pair and the frame-batch path ----
+// sums the loop step of this flavour consumes: the reference flavour reads [0..12] only
+static int loop_nsum(const icpk_params* p) {
+  return p->solve == ICPK_SOLVE_POINT_TO_PLANE ? NP2L : (p->solve == ICPK_SOLVE_REFERENCE ? NSUM_REF : NSUM);
+}
+
+// initial LoopState -> device (on ctx->stream), stop flags armed
+static int device_loop_begin(icpk_ctx* ctx, const icpk_params* p) {
   LoopState* h = ctx->st_host;
   std::memset(h, 0, offsetof(LoopState, trace_R));
   h->Trot[0] = h->Trot[4] = h->Trot[8] = 1.f;
@@ -920,20 +1003,89 @@ static int align_device_loop(icpk_ctx* ctx, const icpk_params* p, float T_out[16
   std::memcpy(h->last_rotation, p->last_rotation, sizeof(h->last_rotation));
   std::memcpy(h->last_translation, p->last_translation, sizeof(h->last_translation));
   ICPK_HIP(ctx, hipMemcpyAsync(ctx->st_dev, h, offsetof(LoopState, trace_R), hipMemcpyHostToDevice, ctx->stream));
-
-  struct Guard {  // the stop flags are only meaningful while this alignment is being enqueued
-    icpk_ctx* c;
-    ~Guard() {
-      c->stop = nullptr;
-      c->st_active = nullptr;
-      c->grid_chain = false;
-    }
-  } guard{ctx};
+  const int nsum = loop_nsum(p);
+  ctx->loop_nact = nsum == NSUM_REF ? NSUM_REF : NSUM;
+  // the stop flags are only meaningful while this alignment is being enqueued
   ctx->stop = &ctx->st_dev->done;
   ctx->st_active = ctx->st_dev;
   ctx->grid_chain = false;
+  ctx->best_of_sweep.clear();
+  return ICPK_OK;
+}
 
-  std::vector<nn_key_t*> best_of_sweep;
+static void device_loop_disarm(icpk_ctx* ctx) {
+  ctx->stop = nullptr;
+  ctx->st_active = nullptr;
+  ctx->grid_chain = false;
+}
+
+// after the LoopState has landed in ctx->st_host: outputs of the alignment
+static int device_loop_finish(icpk_ctx* ctx, const icpk_params* p, float T_out[16], icpk_stats* stats) {
+  device_loop_disarm(ctx);
+  const LoopState* h = ctx->st_host;
+  // the associations of the last EXECUTED sweep are the result
+  const int k = h->sweeps;
+  if (k >= 1 && k <= (int)ctx->best_of_sweep.size()) {
+    nn_key_t* fin = ctx->best_of_sweep[k - 1];
+    if (fin != ctx->best) {
+      ctx->seed = ctx->best;
+      ctx->best = fin;
+    }
+  }
+  ctx->have_seed_m = false;  // the Morton-ordered copy may belong to a skipped sweep: re-gather on demand
+  const int it = h->iterations;
+  if (p->solve == ICPK_SOLVE_REFERENCE) {
+    for (int r = 0; r < 3; ++r) {
+      for (int c = 0; c < 3; ++c) T_out[4 * r + c] = h->Trot[3 * r + c];
+      T_out[4 * r + 3] = h->offset[r];  // icp.cpp:266-268
+    }
+  } else {
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 4; ++c) T_out[4 * r + c] = (float)h->Tk[4 * r + c];
+  }
+  T_out[12] = T_out[13] = T_out[14] = 0.f;
+  T_out[15] = 1.f;
+  ctx->trace_R.assign(h->trace_R, h->trace_R + 9 * it);
+  ctx->trace_t.assign(h->trace_t, h->trace_t + 3 * it);
+  ctx->trace_mse.assign(h->trace_mse, h->trace_mse + it);
+  ctx->trace_pairs.assign(h->trace_pairs, h->trace_pairs + it);
+  if (stats) {
+    stats->iterations = it;
+    stats->status = h->status;
+    stats->final_pairs = (int32_t)h->pairs;
+    stats->final_mse = h->mse;
+    stats->nn_launches = k;
+  }
+  return h->status;
+}
+
+// Whole alignment enqueued up front; loop test, solve and pose accumulation run on the
+// device (kernels_loop.hip).  Same results as the host loop below.
+static int align_device_loop(icpk_ctx* ctx, const icpk_params* p, float T_out[16], icpk_stats* stats) {
+  const bool prof = p->profile != 0;
+  const bool prof_all = p->profile >= 2;  // 1: NN kernels only (2 events per sweep); 2: every stage
+  const bool p2l = p->solve == ICPK_SOLVE_POINT_TO_PLANE;
+  const bool fused = p->nn_mode == ICPK_NN_PRUNED || p->nn_mode == ICPK_NN_GRID;  // K3 runs inside the sweep
+  const int nsum = loop_nsum(p);
+  const int B = red_blocks(ctx->src.n);
+  size_t nev = 0;
+  std::vector<size_t> ev_nn, ev_red, ev_tr;
+  auto stamp = [&](std::vector<size_t>* list) -> int {
+    if (!prof) return ICPK_OK;
+    hipEvent_t e = get_event(ctx, nev);
+    if (!e) return fail(ctx, ICPK_E_HIP, "hipEventCreate failed");
+    ICPK_HIP(ctx, hipEventRecord(e, ctx->stream));
+    if (list) list->push_back(nev);
+    ++nev;
+    return ICPK_OK;
+  };
+  struct Guard {
+    icpk_ctx* c;
+    ~Guard() { device_loop_disarm(c); }
+  } guard{ctx};
+  int rc = device_loop_begin(ctx, p);
+  if (rc) return rc;
+
   int nsweep = 0;
   const int phase = ctx->profile_phase++;  // successive alignments bracket different sweeps: unbiased sample
   auto sweep = [&]() -> int {
@@ -949,7 +1101,7 @@ static int align_device_loop(icpk_ctx* ctx, const icpk_params* p, float T_out[16
     }
     int r = enqueue_nn(ctx, p->nn_mode, e0, e1);
     if (r) return r;
-    best_of_sweep.push_back(ctx->best);
+    ctx->best_of_sweep.push_back(ctx->best);
     if (prof_all) {
       r = stamp(&ev_red);
       if (r) return r;
@@ -958,7 +1110,7 @@ static int align_device_loop(icpk_ctx* ctx, const icpk_params* p, float T_out[16
     if (r) return r;
     return prof_all ? stamp(nullptr) : ICPK_OK;
   };
-  int rc = sweep();  // icp.cpp:98
+  rc = sweep();  // icp.cpp:98
   if (rc) return rc;
   for (int i = 0; i < p->max_iterations; ++i) {
     launch_loop_step(ctx->partial, ctx->pcount, B, nsum, ctx->st_dev, 0, ctx->stream);
@@ -978,39 +1130,11 @@ static int align_device_loop(icpk_ctx* ctx, const icpk_params* p, float T_out[16
   }
   launch_loop_step(ctx->partial, ctx->pcount, B, nsum, ctx->st_dev, 1, ctx->stream);
   ICPK_HIP(ctx, hipGetLastError());
-  ICPK_HIP(ctx, hipMemcpyAsync(h, ctx->st_dev, sizeof(LoopState), hipMemcpyDeviceToHost, ctx->stream));
+  ICPK_HIP(ctx, hipMemcpyAsync(ctx->st_host, ctx->st_dev, sizeof(LoopState), hipMemcpyDeviceToHost, ctx->stream));
   ICPK_HIP(ctx, hipStreamSynchronize(ctx->stream));
 
-  // the associations of the last EXECUTED sweep are the result
-  const int k = h->sweeps;
-  if (k >= 1 && k <= (int)best_of_sweep.size()) {
-    nn_key_t* fin = best_of_sweep[k - 1];
-    if (fin != ctx->best) {
-      ctx->seed = ctx->best;
-      ctx->best = fin;
-    }
-  }
-  ctx->have_seed_m = false;  // the Morton-ordered copy may belong to a skipped sweep: re-gather on demand
-  const int it = h->iterations;
-  if (p->solve == ICPK_SOLVE_REFERENCE) {
-    for (int r = 0; r < 3; ++r) {
-      for (int c = 0; c < 3; ++c) T_out[4 * r + c] = h->Trot[3 * r + c];
-      T_out[4 * r + 3] = h->offset[r];  // icp.cpp:266-268
-    }
-  } else {
-    for (int r = 0; r < 3; ++r)
-      for (int c = 0; c < 4; ++c) T_out[4 * r + c] = (float)h->Tk[4 * r + c];
-  }
-  ctx->trace_R.assign(h->trace_R, h->trace_R + 9 * it);
-  ctx->trace_t.assign(h->trace_t, h->trace_t + 3 * it);
-  ctx->trace_mse.assign(h->trace_mse, h->trace_mse + it);
-  ctx->trace_pairs.assign(h->trace_pairs, h->trace_pairs + it);
+  rc = device_loop_finish(ctx, p, T_out, stats);
   if (stats) {
-    stats->iterations = it;
-    stats->status = h->status;
-    stats->final_pairs = (int32_t)h->pairs;
-    stats->final_mse = h->mse;
-    stats->nn_launches = k;
     stats->nn_timed_launches = (int32_t)ev_nn.size();
     if (prof && nev >= 2) {
       auto span = [&](size_t a, size_t b) {
@@ -1024,7 +1148,7 @@ static int align_device_loop(icpk_ctx* ctx, const icpk_params* p, float T_out[16
       stats->total_ms = span(0, nev - 1);
     }
   }
-  return h->status;
+  return rc;
 }
 
 int icpk_transform_target(icpk_ctx* ctx, const float R[9], const float t[3]) {
@@ -1051,6 +1175,7 @@ int icpk_transform_target(icpk_ctx* ctx, const float R[9], const float t[3]) {
   ctx->have_dec = false;
   ctx->have_boxes = false;
   ctx->have_grid = false;
+  ctx->grid_phase1 = false;
   ctx->have_seed = false;
   ICPK_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return ICPK_OK;
@@ -1295,26 +1420,273 @@ int icpk_align(icpk_ctx* ctx, const icpk_params* p, float T_out[16], icpk_stats*
   return status;
 }
 
-int icpk_align_batch(icpk_ctx* ctx, int32_t n_pairs, const icpk_pair* pairs, const icpk_params* p, float* T_out,
-                     icpk_stats* stats) {
-  if (!ctx || n_pairs < 0 || (n_pairs > 0 && (!pairs || !T_out)) || !p) return ICPK_E_ARG;
-  int worst = ICPK_OK;
-  for (int32_t b = 0; b < n_pairs; ++b) {
-    int rc = icpk_set_target(ctx, pairs[b].tx, pairs[b].ty, pairs[b].tz, pairs[b].nt);
-    if (rc == ICPK_OK) rc = icpk_set_source(ctx, pairs[b].sx, pairs[b].sy, pairs[b].sz, pairs[b].ns);
-    if (rc == ICPK_OK)
-      rc = icpk_align(ctx, p, T_out + 16 * (size_t)b, stats ? stats + b : nullptr);
-    else {
-      for (int k = 0; k < 16; ++k) T_out[16 * (size_t)b + k] = (k % 5 == 0) ? 1.f : 0.f;
-      if (stats) {
-        std::memset(stats + b, 0, sizeof(icpk_stats));
-        stats[b].status = rc;
+// ---- frame-batch mode (the frame-pair formulation of icp.cpp:541-563) ----------
+// Independent pairs, `batch_group` of them advancing in LOCK STEP: every stage of an iteration is
+// ONE launch for the whole group (K1d and K2 with blockIdx.y = pair, the loop step with one
+// workgroup per pair), so the two small kernels and the launch gaps of the dependent chain
+// sweep -> reduce -> step, which leave most of the GPU idle for a single pair, are shared by the
+// group.  Each pair lives in a slot (a child context: its own clouds, grid, loop state and a
+// stream for its set-up work); two sets of slots alternate so that the set-up of the next group
+// (uploads, grid build, query order) overlaps the loop of the current one.  Results are those
+// of icpk_align on the same pair, bit for bit (same kernels' bodies, same canonical reduction
+// geometry per pair).
+namespace {
+
+struct GroupRun {
+  int first = 0, count = 0, set = 0;  // pairs [first, first + count) live in slots [set * G, ...)
+  std::vector<int> rc;                // per pair: set-up status (< 0: failed, not in the loop)
+};
+
+bool batch_eligible(const icpk_ctx* ctx, const icpk_params* p) {
+  return p->nn_mode == ICPK_NN_GRID && !p->host_loop && !ctx->log_fn && p->profile == 0 &&
+         (p->solve == ICPK_SOLVE_REFERENCE || p->solve == ICPK_SOLVE_KABSCH) && p->max_iterations >= 0 &&
+         p->max_iterations <= LOOP_MAX_ITER;
+}
+
+int ensure_slots(icpk_ctx* ctx, int n) {
+  while ((int)ctx->slots.size() < n) {
+    icpk_ctx* sl = make_context(ctx->device, ctx);
+    if (!sl) return fail(ctx, ICPK_E_HIP, "frame-batch slot allocation failed");
+    ctx->slots.push_back(sl);
+  }
+  return ICPK_OK;
+}
+
+// uploads + everything up to (not including) the first host wait of the pair's set-up
+int slot_setup_phase1(icpk_ctx* sl, const icpk_pair& pr, hipMemcpyKind kind) {
+  int rc = set_target_impl(sl, pr.tx, pr.ty, pr.tz, pr.nt, kind, false);
+  if (rc == ICPK_OK) rc = set_source_impl(sl, pr.sx, pr.sy, pr.sz, pr.ns, kind, false);
+  if (rc) return rc;
+  rc = check_ready(sl);
+  if (rc) return rc;
+  if (sl->src.n <= 0) return ICPK_OK;  // an empty source takes the single-pair path
+  sl->have_seed = false;
+  sl->have_qperm = false;
+  rc = ensure_assoc(sl, sl->src.n);
+  if (rc) return rc;
+  return grid_target_phase1(sl);
+}
+
+// grid of the target (waits for its 36-byte info), query order, scan-order queries and seeds,
+// initial loop state: the slot is then ready for the group's first sweep
+int slot_setup_phase2(icpk_ctx* sl, const icpk_params* p, GridSweepArgs& first) {
+  int rc = device_loop_begin(sl, p);
+  if (rc) return rc;
+  NnArgs a = base_nn_args(sl);
+  NnBoxes bx{};
+  int recheck = 0;
+  rc = prepare_sorted_sweep(sl, ICPK_NN_GRID, a, bx, recheck);
+  if (rc) return rc;
+  first = grid_sweep_args(sl, a, bx);
+  after_grid_sweep(sl);
+  sl->best_of_sweep.push_back(sl->best);
+  ICPK_HIP(sl, hipEventRecord(sl->ready_ev, sl->stream));
+  return ICPK_OK;
+}
+
+ReduceArgs slot_reduce_args(const icpk_ctx* sl) {
+  ReduceArgs r{};
+  r.best = sl->best;
+  r.ax = sl->src.x();
+  r.ay = sl->src.y();
+  r.az = sl->src.z();
+  r.tx = sl->tgt.x();
+  r.ty = sl->tgt.y();
+  r.tz = sl->tgt.z();
+  r.partial = sl->partial;
+  r.pcount = sl->pcount;
+  r.st = sl->st_dev;
+  r.nq = sl->src.n;
+  r.nblocks = red_blocks(sl->src.n);
+  return r;
+}
+
+// the whole loop of a group on the parent's stream, then the read-back of every loop state
+int enqueue_group_loop(icpk_ctx* ctx, const icpk_params* p, const std::vector<icpk_ctx*>& act,
+                       const std::vector<GridSweepArgs>& first, int set) {
+  const int n = (int)act.size();
+  if (n == 0) return ICPK_OK;
+  const int nsum = loop_nsum(p);
+  const int nact = nsum == NSUM_REF ? NSUM_REF : NSUM;
+  long long nq_total = 0;
+  for (icpk_ctx* sl : act) {
+    ICPK_HIP(ctx, hipStreamWaitEvent(ctx->stream, sl->ready_ev, 0));
+    nq_total += sl->src.n;
+  }
+  // lanes per query: a single pair is latency-bound and wants 8; a group that fills the GPU
+  // several times over is issue-bound and does better with fewer, longer lanes (measured on
+  // 8 config-2 pairs: 43.4k iter/s with 8, 50.6k with 4, 48.2k with 2)
+  const int slices = ctx->grid_slices ? ctx->grid_slices : (nq_total >= 300000 ? 4 : 8);
+  GridSweepBatch gb{};
+  ReduceBatch rb{};
+  StepBatch sb{};
+  for (int k = 0; k < n; ++k) {
+    gb.p[k] = first[k];
+    rb.p[k] = slot_reduce_args(act[k]);
+    sb.p[k].partial = act[k]->partial;
+    sb.p[k].pcount = act[k]->pcount;
+    sb.p[k].nblocks = rb.p[k].nblocks;
+    sb.p[k].st = act[k]->st_dev;
+  }
+  launch_nn_grid_batch(gb, n, slices, 1, ctx->stream);  // icp.cpp:98 (expanding search from element 0)
+  launch_assoc_reduce_batch(rb, n, p->max_nn_dist, nact, ctx->stream);
+  for (int i = 0; i < p->max_iterations; ++i) {
+    launch_loop_step_batch(sb, n, nsum, 0, ctx->stream);
+    for (int k = 0; k < n; ++k) {  // pointer rotation only: nothing is enqueued for a chained sweep
+      icpk_ctx* sl = act[k];
+      NnArgs a = base_nn_args(sl);
+      NnBoxes bx{};
+      int recheck = 0;
+      int rc = prepare_sorted_sweep(sl, ICPK_NN_GRID, a, bx, recheck);
+      if (rc) {
+        ctx->err = sl->err;
+        return rc;
       }
+      gb.p[k] = grid_sweep_args(sl, a, bx);
+      after_grid_sweep(sl);
+      sl->best_of_sweep.push_back(sl->best);
+      rb.p[k].best = sl->best;
     }
+    launch_nn_grid_batch(gb, n, slices, 0, ctx->stream);  // icp.cpp:255, K3 fused
+    launch_assoc_reduce_batch(rb, n, p->max_nn_dist, nact, ctx->stream);
+  }
+  launch_loop_step_batch(sb, n, nsum, 1, ctx->stream);
+  ICPK_HIP(ctx, hipGetLastError());
+  for (icpk_ctx* sl : act)
+    ICPK_HIP(ctx, hipMemcpyAsync(sl->st_host, sl->st_dev, sizeof(LoopState), hipMemcpyDeviceToHost, ctx->stream));
+  ICPK_HIP(ctx, hipEventRecord(ctx->group_ev[set], ctx->stream));
+  return ICPK_OK;
+}
+
+void identity16(float* T) {
+  for (int k = 0; k < 16; ++k) T[k] = (k % 5 == 0) ? 1.f : 0.f;
+}
+
+int align_batch_impl(icpk_ctx* ctx, int32_t n_pairs, const icpk_pair* pairs, const icpk_params* p, float* T_out,
+                     icpk_stats* stats, hipMemcpyKind kind) {
+  if (!ctx || n_pairs < 0 || (n_pairs > 0 && (!pairs || !T_out)) || !p) return ICPK_E_ARG;
+  if (p->max_iterations < 0 || p->solve < ICPK_SOLVE_REFERENCE || p->solve > ICPK_SOLVE_POINT_TO_PLANE)
+    return fail(ctx, ICPK_E_ARG, "bad params");
+  ICPK_HIP(ctx, hipSetDevice(ctx->device));
+  int worst = ICPK_OK;
+  auto note = [&](int rc) {
     if (rc < 0 && worst >= 0) worst = rc;
     if (rc > 0 && worst >= 0 && rc > worst) worst = rc;
+  };
+  for (int32_t b = 0; b < n_pairs; ++b) {
+    identity16(T_out + 16 * (size_t)b);
+    if (stats) std::memset(stats + b, 0, sizeof(icpk_stats));
   }
+  auto fetch_assoc = [&](icpk_ctx* c, const icpk_pair& pr) -> int {
+    if (!pr.idx_out && !pr.dist_out) return ICPK_OK;
+    return icpk_get_associations(c, pr.idx_out, pr.dist_out);
+  };
+  if (!batch_eligible(ctx, p)) {
+    // other kernels / flavours / a log callback: the pairs one after the other on this context
+    for (int32_t b = 0; b < n_pairs; ++b) {
+      int rc = set_target_impl(ctx, pairs[b].tx, pairs[b].ty, pairs[b].tz, pairs[b].nt, kind);
+      if (rc == ICPK_OK) rc = set_source_impl(ctx, pairs[b].sx, pairs[b].sy, pairs[b].sz, pairs[b].ns, kind);
+      if (rc == ICPK_OK) {
+        rc = icpk_align(ctx, p, T_out + 16 * (size_t)b, stats ? stats + b : nullptr);
+        if (rc >= 0) {
+          const int r2 = fetch_assoc(ctx, pairs[b]);
+          if (r2 < 0) rc = r2;
+        }
+      } else if (stats) {
+        stats[b].status = rc;
+      }
+      note(rc);
+    }
+    return worst;
+  }
+
+  const int G = ctx->batch_group < 1 ? 1 : (ctx->batch_group > BATCH_MAX ? BATCH_MAX : ctx->batch_group);
+  const int ngroups = (n_pairs + G - 1) / G;
+  int rc = ensure_slots(ctx, ngroups > 1 ? 2 * G : (n_pairs < G ? n_pairs : G));
+  if (rc) return rc;
+
+  auto finish_group = [&](const GroupRun& g) -> int {
+    bool any = false;
+    for (int k = 0; k < g.count; ++k) any |= g.rc[k] == ICPK_OK;
+    if (any) ICPK_HIP(ctx, hipEventSynchronize(ctx->group_ev[g.set]));
+    for (int k = 0; k < g.count; ++k) {
+      const int b = g.first + k;
+      icpk_ctx* sl = ctx->slots[(size_t)g.set * G + k];
+      int r = g.rc[k];
+      if (r == ICPK_OK) {
+        r = device_loop_finish(sl, p, T_out + 16 * (size_t)b, stats ? stats + b : nullptr);
+        if (r >= 0) {
+          const int r2 = fetch_assoc(sl, pairs[b]);
+          if (r2 < 0) r = r2;
+        }
+      } else if (r >= 100) {  // ran on the single-pair path during set-up: outputs already written
+        r -= 100;
+      } else if (stats) {
+        stats[b].status = r;
+      }
+      if (r < 0) ctx->err = sl->err;
+      note(r);
+    }
+    return ICPK_OK;
+  };
+
+  GroupRun prev;
+  bool have_prev = false;
+  for (int gi = 0; gi < ngroups; ++gi) {
+    GroupRun g;
+    g.first = gi * G;
+    g.count = n_pairs - g.first < G ? n_pairs - g.first : G;
+    g.set = ngroups > 1 ? (gi & 1) : 0;
+    g.rc.assign(g.count, ICPK_OK);
+    for (int k = 0; k < g.count; ++k)
+      g.rc[k] = slot_setup_phase1(ctx->slots[(size_t)g.set * G + k], pairs[g.first + k], kind);
+    std::vector<icpk_ctx*> act;
+    std::vector<GridSweepArgs> first;
+    for (int k = 0; k < g.count; ++k) {
+      if (g.rc[k] != ICPK_OK) continue;
+      icpk_ctx* sl = ctx->slots[(size_t)g.set * G + k];
+      const int b = g.first + k;
+      if (sl->src.n <= 0) {  // no queries: the single-pair path handles it (icp.cpp:163-182 fallback)
+        const int r = icpk_align(sl, p, T_out + 16 * (size_t)b, stats ? stats + b : nullptr);
+        g.rc[k] = r < 0 ? r : 100 + r;
+        continue;
+      }
+      GridSweepArgs fa{};
+      g.rc[k] = slot_setup_phase2(sl, p, fa);
+      if (g.rc[k] != ICPK_OK) {
+        device_loop_disarm(sl);
+        continue;
+      }
+      act.push_back(sl);
+      first.push_back(fa);
+    }
+    rc = enqueue_group_loop(ctx, p, act, first, g.set);
+    if (rc) {  // enqueue failed: nothing of this group can be trusted
+      for (icpk_ctx* sl : act) device_loop_disarm(sl);
+      (void)hipStreamSynchronize(ctx->stream);
+      return rc;
+    }
+    if (have_prev) finish_group(prev);
+    prev = g;
+    have_prev = true;
+  }
+  if (have_prev) finish_group(prev);
+  // host input buffers were read asynchronously: everything has landed before we return
+  ICPK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (icpk_ctx* sl : ctx->slots) ICPK_HIP(ctx, hipStreamSynchronize(sl->stream));
   return worst;
+}
+
+}  // namespace
+
+int icpk_align_batch(icpk_ctx* ctx, int32_t n_pairs, const icpk_pair* pairs, const icpk_params* p, float* T_out,
+                     icpk_stats* stats) {
+  return align_batch_impl(ctx, n_pairs, pairs, p, T_out, stats, hipMemcpyHostToDevice);
+}
+
+int icpk_align_batch_device(icpk_ctx* ctx, int32_t n_pairs, const icpk_pair* pairs, const icpk_params* p,
+                            float* T_out, icpk_stats* stats) {
+  return align_batch_impl(ctx, n_pairs, pairs, p, T_out, stats, hipMemcpyDeviceToDevice);
 }
 
 static int backproject_impl(icpk_ctx* ctx, const uint16_t* depth, int32_t rows, int32_t cols, float fx, float cx,
@@ -1370,7 +1742,7 @@ static int backproject_impl(icpk_ctx* ctx, const uint16_t* depth, int32_t rows, 
   ctx->have_seed = false;
   ctx->have_qperm = false;
   if (which == 1) {
-    ctx->have_dec = ctx->have_boxes = ctx->have_grid = false;
+    ctx->have_dec = ctx->have_boxes = ctx->have_grid = ctx->grid_phase1 = false;
     ctx->have_normals = normals_mode >= 0;
     if (ctx->have_normals) ctx->nrm.n = n;
   }

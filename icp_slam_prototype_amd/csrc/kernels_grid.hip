@@ -230,23 +230,12 @@ extern "C" int icpk_debug_clear_grid_stamps() {
 // a single pair (arguments by value); nn_grid_batch_kernel runs blockIdx.y-many independent
 // pairs in lock step (frame-batch mode): same code, same results.
 template <int S, bool EXPAND>
-__device__ __forceinline__ void nn_grid_body(const GridSweepArgs& ga, const int block) {
-  float* __restrict__ const qxp = ga.qx;
-  float* __restrict__ const qyp = ga.qy;
-  float* __restrict__ const qzp = ga.qz;
-  const int nq = ga.nq;
-  float4* __restrict__ const qm4 = ga.qm4;
-  const float4* __restrict__ const t4 = ga.t4;
-  const int* __restrict__ const cell_start = ga.cell_start;
-  const GridInfo* __restrict__ const gi = ga.gi;
-  const float* __restrict__ const oxp = ga.ox;
-  const float* __restrict__ const oyp = ga.oy;
-  const float* __restrict__ const ozp = ga.oz;
-  const float4* __restrict__ const sp_in = ga.sp_in;
-  float4* __restrict__ const sp_out = ga.sp_out;
-  nn_key_t* __restrict__ const best = ga.best;
-  nn_key_t* __restrict__ const best_m = ga.best_m;
-  const LoopState* __restrict__ const st = ga.st;
+__device__ __forceinline__ void nn_grid_body(
+    float* __restrict__ qxp, float* __restrict__ qyp, float* __restrict__ qzp, const int nq, float4* __restrict__ qm4,
+    const float4* __restrict__ t4, const int* __restrict__ cell_start, const GridInfo* __restrict__ gi,
+    const float* __restrict__ oxp, const float* __restrict__ oyp, const float* __restrict__ ozp,
+    const float4* __restrict__ sp_in, float4* __restrict__ sp_out, nn_key_t* __restrict__ best,
+    nn_key_t* __restrict__ best_m, const LoopState* __restrict__ st, const int block) {
   // qm4: the queries in scan order (by grid cell), (x, y, z, original index) -- one coalesced
   // 16-byte load instead of the qperm -> coordinates chain; kept in step with the caller's
   // planes here.  sp_in / sp_out: the seed of every query as a point (x, y, z, target index) in
@@ -467,7 +456,8 @@ __device__ __forceinline__ void nn_grid_body(const GridSweepArgs& ga, const int 
 
 template <int S, bool EXPAND>
 __global__ __launch_bounds__(ICPK_GRID_BLOCK) void nn_grid_kernel(const GridSweepArgs a) {
-  nn_grid_body<S, EXPAND>(a, blockIdx.x);
+  nn_grid_body<S, EXPAND>(a.qx, a.qy, a.qz, a.nq, a.qm4, a.t4, a.cell_start, a.gi, a.ox, a.oy, a.oz, a.sp_in, a.sp_out,
+                          a.best, a.best_m, a.st, blockIdx.x);
 }
 
 // frame-batch mode: blockIdx.y = pair.  The pairs of a group differ in size: workgroups beyond
@@ -476,7 +466,8 @@ template <int S, bool EXPAND>
 __global__ __launch_bounds__(ICPK_GRID_BLOCK) void nn_grid_batch_kernel(const GridSweepBatch b) {
   const GridSweepArgs& a = b.p[blockIdx.y];
   if ((long long)blockIdx.x * (64 / S) >= a.nq) return;
-  nn_grid_body<S, EXPAND>(a, blockIdx.x);
+  nn_grid_body<S, EXPAND>(a.qx, a.qy, a.qz, a.nq, a.qm4, a.t4, a.cell_start, a.gi, a.ox, a.oy, a.oz, a.sp_in, a.sp_out,
+                          a.best, a.best_m, a.st, blockIdx.x);
 }
 
 static inline int grid_blocks(int nq, int slices) { return (nq + (64 / slices) - 1) / (64 / slices); }
@@ -517,6 +508,8 @@ void launch_nn_grid_batch(const GridSweepBatch& b, int count, int slices, int ex
     }                      \
   } while (0)
   switch (slices) {
+    case 1: ICPK_LAUNCH(1); break;
+    case 2: ICPK_LAUNCH(2); break;
     case 4: ICPK_LAUNCH(4); break;
     default: ICPK_LAUNCH(8); break;
   }

@@ -91,9 +91,8 @@ __device__ void compose_rt(const float Rf[9], const float tf[3], double Tk[12]) 
 }
 
 template <int NS, int NACT = NS>
-__global__ __launch_bounds__(256) void loop_step_kernel(const double* __restrict__ partial,
-                                                        const int* __restrict__ pcount, int nblocks,
-                                                        LoopState* __restrict__ st, int stats_only) {
+__device__ __forceinline__ void loop_step_body(const double* __restrict__ partial, const int* __restrict__ pcount,
+                                               int nblocks, LoopState* __restrict__ st, int stats_only) {
   // the control words are fetched together with the partial sums (independent loads in
   // flight at once) and only then acted upon
   const int done = st->done, stop_after = st->stop_after_transform, i = st->iterations;
@@ -192,6 +191,20 @@ __global__ __launch_bounds__(256) void loop_step_kernel(const double* __restrict
   STEP_STAMP(i, 4);
 }
 
+template <int NS, int NACT = NS>
+__global__ __launch_bounds__(256) void loop_step_kernel(const double* __restrict__ partial,
+                                                        const int* __restrict__ pcount, int nblocks,
+                                                        LoopState* __restrict__ st, int stats_only) {
+  loop_step_body<NS, NACT>(partial, pcount, nblocks, st, stats_only);
+}
+
+// frame-batch mode: one workgroup per pair
+template <int NS, int NACT = NS>
+__global__ __launch_bounds__(256) void loop_step_batch_kernel(const StepBatch b, int stats_only) {
+  const StepArgs& a = b.p[blockIdx.x];
+  loop_step_body<NS, NACT>(a.partial, a.pcount, a.nblocks, a.st, stats_only);
+}
+
 void launch_loop_step(const double* partial, const int* pcount, int nblocks, int nsum, LoopState* st, int stats_only,
                       hipStream_t s) {
   if (nsum == NP2L)
@@ -201,6 +214,14 @@ void launch_loop_step(const double* partial, const int* pcount, int nblocks, int
                        stats_only);
   else
     hipLaunchKernelGGL(loop_step_kernel<NSUM>, dim3(1), dim3(256), 0, s, partial, pcount, nblocks, st, stats_only);
+}
+
+void launch_loop_step_batch(const StepBatch& b, int count, int nsum, int stats_only, hipStream_t s) {
+  if (count <= 0) return;
+  if (nsum == NSUM_REF)
+    hipLaunchKernelGGL((loop_step_batch_kernel<NSUM, NSUM_REF>), dim3(count), dim3(256), 0, s, b, stats_only);
+  else
+    hipLaunchKernelGGL(loop_step_batch_kernel<NSUM>, dim3(count), dim3(256), 0, s, b, stats_only);
 }
 
 // K3 with the transform taken from the loop state (same arithmetic as transform_kernel)

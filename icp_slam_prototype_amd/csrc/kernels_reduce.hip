@@ -33,25 +33,28 @@ extern "C" int icpk_debug_read_red_stamps(unsigned long long* out) {
 // NACT: how many of the NSUM sums the consumer needs.  icpk_reduce and the Kabsch flavour take
 // all 19; the reference flavour's loop step only reads [0..12] (M, mean difference, distance
 // sum), so the device loop skips the sums of a and b: a third less butterfly.
+// `block` of `nblocks` (the canonical geometry of the pair: nblocks = red_blocks(nq)); shared
+// by the single-pair kernel and the frame-batch kernel (blockIdx.y = pair).
 template <int NACT>
-__global__ __launch_bounds__(RED_THREADS) void assoc_reduce_kernel(
+__device__ __forceinline__ void assoc_reduce_body(
     const nn_key_t* __restrict__ best, const float* __restrict__ ax, const float* __restrict__ ay,
     const float* __restrict__ az, int nq, const float* __restrict__ tx, const float* __restrict__ ty,
     const float* __restrict__ tz, float max_dist, int32_t* __restrict__ idx_out, float* __restrict__ dist_out,
-    double* __restrict__ partial, int* __restrict__ pcount, LoopState* __restrict__ st) {
+    double* __restrict__ partial, int* __restrict__ pcount, LoopState* __restrict__ st, const int block,
+    const int nblocks) {
   if (st) {
     if (st->done | st->stop_after_transform) return;
-    if (blockIdx.x == 0 && threadIdx.x == 0) st->sweeps += 1;  // this sweep's associations are consumed
+    if (block == 0 && threadIdx.x == 0) st->sweeps += 1;  // this sweep's associations are consumed
   }
   const int tid = threadIdx.x;
-  const int P = gridDim.x * RED_THREADS;
+  const int P = nblocks * RED_THREADS;
   RED_STAMP(0);
   double v[NACT];
 #pragma unroll
   for (int s = 0; s < NACT; ++s) v[s] = 0.0;
   int cnt = 0;
 
-  for (int i = blockIdx.x * RED_THREADS + tid; i < nq; i += P) {
+  for (int i = block * RED_THREADS + tid; i < nq; i += P) {
     const nn_key_t key = best[i];
     const float d = __uint_as_float((unsigned)(key >> 32));
     const int j = (int)(unsigned)(key & 0xffffffffu);
@@ -92,9 +95,29 @@ __global__ __launch_bounds__(RED_THREADS) void assoc_reduce_kernel(
     wc[wave] = cnt;
   }
   __syncthreads();
-  if (tid < NACT) partial[tid * RED_MAX_BLOCKS + blockIdx.x] = ((ws[0][tid] + ws[1][tid]) + ws[2][tid]) + ws[3][tid];
-  if (tid == NACT) pcount[blockIdx.x] = wc[0] + wc[1] + wc[2] + wc[3];
+  if (tid < NACT) partial[tid * RED_MAX_BLOCKS + block] = ((ws[0][tid] + ws[1][tid]) + ws[2][tid]) + ws[3][tid];
+  if (tid == NACT) pcount[block] = wc[0] + wc[1] + wc[2] + wc[3];
   RED_STAMP(3);
+}
+
+template <int NACT>
+__global__ __launch_bounds__(RED_THREADS) void assoc_reduce_kernel(
+    const nn_key_t* __restrict__ best, const float* __restrict__ ax, const float* __restrict__ ay,
+    const float* __restrict__ az, int nq, const float* __restrict__ tx, const float* __restrict__ ty,
+    const float* __restrict__ tz, float max_dist, int32_t* __restrict__ idx_out, float* __restrict__ dist_out,
+    double* __restrict__ partial, int* __restrict__ pcount, LoopState* __restrict__ st) {
+  assoc_reduce_body<NACT>(best, ax, ay, az, nq, tx, ty, tz, max_dist, idx_out, dist_out, partial, pcount, st,
+                          blockIdx.x, gridDim.x);
+}
+
+// frame-batch mode: blockIdx.y = pair; every pair keeps ITS canonical geometry (its own
+// nblocks), so its sums equal those of a single-pair launch bit for bit
+template <int NACT>
+__global__ __launch_bounds__(RED_THREADS) void assoc_reduce_batch_kernel(const ReduceBatch b, float max_dist) {
+  const ReduceArgs& a = b.p[blockIdx.y];
+  if ((int)blockIdx.x >= a.nblocks) return;
+  assoc_reduce_body<NACT>(a.best, a.ax, a.ay, a.az, a.nq, a.tx, a.ty, a.tz, max_dist, nullptr, nullptr, a.partial,
+                          a.pcount, a.st, blockIdx.x, a.nblocks);
 }
 
 // K5: normal equations of the linearised point-to-plane step (extension; the
@@ -186,6 +209,16 @@ void launch_assoc_reduce(const nn_key_t* best, const float* ax, const float* ay,
     hipLaunchKernelGGL(assoc_reduce_kernel<NSUM>, dim3(B), dim3(RED_THREADS), 0, s, best, ax, ay, az, nq, tx, ty, tz,
                        max_dist, idx_out, dist_out, partial, pcount, st);
   if (out) launch_reduce_final(partial, pcount, B, NSUM, out, s);
+}
+
+void launch_assoc_reduce_batch(const ReduceBatch& b, int count, float max_dist, int nact, hipStream_t s) {
+  int bmax = 0;
+  for (int k = 0; k < count; ++k) bmax = b.p[k].nblocks > bmax ? b.p[k].nblocks : bmax;
+  if (count <= 0 || bmax <= 0) return;
+  if (nact == NSUM_REF)
+    hipLaunchKernelGGL(assoc_reduce_batch_kernel<NSUM_REF>, dim3(bmax, count), dim3(RED_THREADS), 0, s, b, max_dist);
+  else
+    hipLaunchKernelGGL(assoc_reduce_batch_kernel<NSUM>, dim3(bmax, count), dim3(RED_THREADS), 0, s, b, max_dist);
 }
 
 }  // namespace icpk

@@ -16,9 +16,11 @@
 #define ICPK_HD inline
 #endif
 
-#include "solve.h"
-
 namespace icpk {
+
+struct Mat3 {
+  double m[3][3];
+};
 
 namespace detail {
 
@@ -115,13 +117,83 @@ ICPK_HD void svd3(const Mat3& A, Mat3& U, double S[3], Mat3& V) {
   }
 }
 
+// ---- orthogonal polar factor by Newton's iteration ------------------------------------------
+// The rotation both solve flavours want is the orthogonal polar factor of the 3x3 moment:
+// A = U S V^T  =>  Q = U V^T (A = Q P, P symmetric positive semi-definite), independent of the
+// SVD algorithm and its sign conventions whenever A is non-singular.  Newton's iteration
+//     Q <- (g Q + (g Q)^-T) / 2,   (g Q)^-T = cof(Q) / (g det Q),
+// with determinantal scaling g ~ |det Q|^(-1/3) rounded to a power of two (exact), reaches it in
+// 6-9 steps of ONE division each, against ~15 plane rotations of 3 divisions + 2 square roots for
+// the Jacobi SVD above (4 us of the device loop's single-lane step at 92k points).  After an
+// unscaled step every singular value is >= 1, so det - 1 bounds the distance to orthogonality:
+// once g == 1 and |det| - 1 <= 1e-8 the next iterate is orthogonal to ~1e-16.
+// Only +, -, *, /, fma and exponent-field arithmetic: bit-identical on host and device.
+// Returns false (caller falls back to svd3) when A is not safely invertible: a non-finite or
+// tiny / huge entry, |det| < 1e-7 after scaling the largest entry to [1, 2) (cond ~> 1e7:
+// rank-deficient moments such as an exactly planar centred cloud), or no convergence.
+ICPK_HD int exp2_floor(double x) {  // floor(log2 x) of a positive normal double
+  uint64_t u;
+  std::memcpy(&u, &x, sizeof(u));
+  return (int)((u >> 52) & 0x7ffu) - 1023;
+}
+ICPK_HD double pow2i(int e) {  // 2^e, -1022 <= e <= 1023
+  const uint64_t u = (uint64_t)(e + 1023) << 52;
+  double d;
+  std::memcpy(&d, &u, sizeof(d));
+  return d;
+}
+
+ICPK_HD bool polar3(const double A[9], double Q[9]) {
+  double amax = 0.0;
+  for (int k = 0; k < 9; ++k) {
+    const double v = std::fabs(A[k]);
+    if (!(v <= 1e290)) return false;  // inf / NaN / absurd
+    amax = v > amax ? v : amax;
+  }
+  if (!(amax >= 1e-290)) return false;
+  const double s0 = pow2i(-exp2_floor(amax));  // largest entry -> [1, 2)
+  for (int k = 0; k < 9; ++k) Q[k] = A[k] * s0;
+  for (int it = 0; it < 40; ++it) {
+    double c[9];
+    c[0] = __builtin_fma(Q[4], Q[8], -(Q[5] * Q[7]));
+    c[1] = __builtin_fma(Q[5], Q[6], -(Q[3] * Q[8]));
+    c[2] = __builtin_fma(Q[3], Q[7], -(Q[4] * Q[6]));
+    c[3] = __builtin_fma(Q[7], Q[2], -(Q[8] * Q[1]));
+    c[4] = __builtin_fma(Q[8], Q[0], -(Q[6] * Q[2]));
+    c[5] = __builtin_fma(Q[6], Q[1], -(Q[7] * Q[0]));
+    c[6] = __builtin_fma(Q[1], Q[5], -(Q[2] * Q[4]));
+    c[7] = __builtin_fma(Q[2], Q[3], -(Q[0] * Q[5]));
+    c[8] = __builtin_fma(Q[0], Q[4], -(Q[1] * Q[3]));
+    const double det = __builtin_fma(Q[2], c[2], __builtin_fma(Q[1], c[1], Q[0] * c[0]));
+    const double ad = std::fabs(det);
+    if (it == 0 && !(ad >= 1e-7)) return false;
+    if (!(ad >= 1e-30) || !(ad <= 1e30)) return false;
+    const int ed = exp2_floor(ad);                                  // |det| in [2^ed, 2^(ed+1))
+    const int eg = ed >= 0 ? -((ed + 1) / 3) : ((1 - ed) / 3);     // ~ -ed/3; 0 for |det| in [1/2, 4)
+    const bool last = it > 0 && eg == 0 && ad - 1.0 <= 1e-8;  // (it > 0: Q is then a Newton iterate)
+    const double hg = pow2i(eg - 1);                 // g / 2
+    const double hinv = 0.5 / (det * pow2i(eg));     // 1 / (2 g det)
+    for (int k = 0; k < 9; ++k) Q[k] = __builtin_fma(hg, Q[k], hinv * c[k]);
+    if (last) return true;
+  }
+  return false;
+}
+
 ICPK_HD void solve_reference(const float M[9], float R[9]) {
-  Mat3 A, U, V;
-  double S[3], Rd[9];
-  for (int r = 0; r < 3; ++r)
-    for (int c = 0; c < 3; ++c) A.m[r][c] = M[3 * r + c];
-  svd3(A, U, S, V);
-  v_ut(V, U, Rd);  // icp.cpp:218  R = svd.vt.t() * svd.u.t()
+  double Ad[9], Qd[9], Rd[9];
+  for (int k = 0; k < 9; ++k) Ad[k] = M[k];
+  if (polar3(Ad, Qd)) {
+    // icp.cpp:215-218  R = svd.vt.t() * svd.u.t() = V U^T = (U V^T)^T
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) Rd[3 * r + c] = Qd[3 * c + r];
+  } else {  // (near-)singular moment: the SVD's completion of the null directions
+    Mat3 A, U, V;
+    double S[3];
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) A.m[r][c] = M[3 * r + c];
+    svd3(A, U, S, V);
+    v_ut(V, U, Rd);
+  }
   double Rf[9];
   for (int k = 0; k < 9; ++k) {
     R[k] = (float)Rd[k];
@@ -168,14 +240,22 @@ ICPK_HD void solve_kabsch(int64_t n, const double sa[3], const double sb[3], con
     cb[k] = sb[k] / (double)n;
   }
   Mat3 H, U, V;
-  double S[3];
+  double S[3], Hd[9], Qd[9];
   for (int r = 0; r < 3; ++r)
-    for (int c = 0; c < 3; ++c) H.m[r][c] = sab[3 * r + c] - (double)n * ca[r] * cb[c];  // :18-22 AA^T BB
-  svd3(H, U, S, V);
-  v_ut(V, U, R);        // :28  R = Vt.T * U.T
-  if (det9(R) < 0) {    // :31-34 negate the last row of Vt
-    for (int r = 0; r < 3; ++r) V.m[r][2] = -V.m[r][2];
-    v_ut(V, U, R);
+    for (int c = 0; c < 3; ++c) Hd[3 * r + c] = H.m[r][c] = sab[3 * r + c] - (double)n * ca[r] * cb[c];  // :18-22 AA^T BB
+  // :26-28  U,S,Vt = svd(H); R = Vt.T * U.T = (U V^T)^T: the polar factor transposed, when it is
+  // a proper rotation (det H > 0); the reflection branch (:31-34) flips the SMALLEST singular
+  // direction, which only the SVD knows
+  if (det9(Hd) > 0 && polar3(Hd, Qd)) {
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) R[3 * r + c] = Qd[3 * c + r];
+  } else {
+    svd3(H, U, S, V);
+    v_ut(V, U, R);        // :28  R = Vt.T * U.T
+    if (det9(R) < 0) {    // :31-34 negate the last row of Vt
+      for (int r = 0; r < 3; ++r) V.m[r][2] = -V.m[r][2];
+      v_ut(V, U, R);
+    }
   }
   for (int r = 0; r < 3; ++r) t[r] = -(R[3 * r] * ca[0] + R[3 * r + 1] * ca[1] + R[3 * r + 2] * ca[2]) + cb[r];  // :36
 }

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ICPK_VERSION_STRING "icpk 0.1.0 (gfx950)"
+#define ICPK_VERSION_STRING "icpk 0.2.0 (gfx950)"
 
 /* ---- status codes -------------------------------------------------------- */
 #define ICPK_OK 0
@@ -126,12 +126,17 @@ typedef struct icpk_stats {
   float total_ms;           /* first to last recorded event                       */
 } icpk_stats;
 
-/* One frame pair for icpk_align_batch (host pointers, SoA). */
+/* One frame pair for icpk_align_batch (xyz-SoA: host pointers; icpk_align_batch_device:
+ * device pointers on the context's device).  idx_out / dist_out: optional HOST arrays of ns
+ * entries that receive the pair's final associations (as icpk_get_associations); NULL = not
+ * wanted. */
 typedef struct icpk_pair {
   const float *sx, *sy, *sz;
   int32_t ns;
   const float *tx, *ty, *tz;
   int32_t nt;
+  int32_t *idx_out;
+  float *dist_out;
 } icpk_pair;
 
 /* same shape as logDeltaTime(int logKey, int quantity) (SLAM.hpp:30,
@@ -204,11 +209,21 @@ int icpk_align(icpk_ctx *ctx, const icpk_params *p, float T_out[16], icpk_stats 
  * Arrays sized for params.max_iterations entries; any may be NULL. */
 int icpk_get_trace(icpk_ctx *ctx, int32_t *n_iter, float *R_out, float *t_out, int32_t *pairs_out,
                    float *mse_out);
-/* frame-batch mode: n_pairs independent pairs, one after the
- * other on this context's device; T_out n_pairs x 16, stats n_pairs (or NULL).
+/* frame-batch mode (the frame-pair formulation of icp.cpp:541-563): n_pairs
+ * independent pairs on this context's device; T_out n_pairs x 16, stats n_pairs (or NULL).
+ * With the default kernels (ICPK_NN_GRID, device-side loop, reference or Kabsch flavour) up to
+ * ICPK_BATCH_GROUP (default 8, at most 16) pairs advance in lock step -- one launch per stage
+ * for the whole group -- while the next group is being uploaded and indexed; every pair's
+ * result equals icpk_align on that pair bit for bit.  Other settings run the pairs one after
+ * the other.  The context's own clouds are not touched by the lock-step path.  Per-launch
+ * timings (params.profile) are not collected in this mode.
  * Returns the first negative status, else the max status. */
 int icpk_align_batch(icpk_ctx *ctx, int32_t n_pairs, const icpk_pair *pairs,
                      const icpk_params *p, float *T_out, icpk_stats *stats);
+/* same with the clouds already resident in HBM (sx..tz are device pointers; copied
+ * device-to-device into the slots, so the caller's buffers stay untouched) */
+int icpk_align_batch_device(icpk_ctx *ctx, int32_t n_pairs, const icpk_pair *pairs,
+                            const icpk_params *p, float *T_out, icpk_stats *stats);
 
 /* ---- front end -------------------------------------- */
 /* pointcloud.cpp:19-58 without the rand()%40 subsample: row-major back-
