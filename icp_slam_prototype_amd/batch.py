@@ -1,20 +1,26 @@
-"""Frame-batch mode: independent frame pairs sharded
-block-wise over one process per GPU; no data-path collective per iteration.
+"""Multi-GPU modes, host side above the C ABI.
 
-Collectives (torch.distributed; backend "nccl" is RCCL over xGMI on ROCm, "gloo"
-in the CPU tests):
-  * one broadcast of the shared target cloud (key frame) from rank 0: a 3 x Nt
-    float32 SoA, 1.1 MB at Nt = 92k -- a single latency-bound message;
-  * one all_gather of the per-rank results (B_r x 16 floats + 4 stats).
-The alignment itself is injected (`align_fn`): bench.py passes the C-ABI context;
-the gloo tests pass a CPU stand-in so the sharding/collective logic is covered
-without a GPU.
+Frame-batch mode -- the path shards over independent frame pairs (the frame-pair
+formulation of icp.cpp:541-563): pairs are block-partitioned over one process per GPU, every
+rank aligns its block with icpk_align_batch(_device) (lock-step groups on its GPU), and there is
+NO data-path collective per iteration.  The collectives are
+  * one broadcast of a shared target cloud (key frame), 3 x Nt float32 -- a single
+    latency-bound message over xGMI -- when all pairs share one target;
+  * one all-gather of the results (20 floats per pair).
+
+Two transports implement them:
+  * RcclComm  -- the C ABI's own RCCL communicator (icpk_comm_* in include/icpk.h,
+                 csrc/icpk_comm.cpp): what a C++ host uses, and what bench.py uses on GPUs;
+  * TorchComm -- torch.distributed ("gloo" in the CPU tests and the 1-GPU rehearsal, where
+                 RCCL refuses two ranks on one device; "nccl" is RCCL too).
+The alignment itself is injected where a test needs a CPU stand-in.
 """
 import numpy as np
 
 
 def partition(n_items, world, rank):
-    """Block-wise shard: returns (start, count) of rank's contiguous slice."""
+    """Block-wise shard: returns (start, count) of rank's contiguous slice (the same rule as
+    icpk_comm_partition)."""
     if world <= 0 or not (0 <= rank < world) or n_items < 0:
         raise ValueError("bad partition arguments")
     base, rem = divmod(n_items, world)
@@ -22,63 +28,140 @@ def partition(n_items, world, rank):
     return start, base + (1 if rank < rem else 0)
 
 
-def broadcast_cloud(cloud, src, device, dist):
-    """Broadcast a (3, N) float32 cloud from rank `src`; other ranks pass None.
-    Returns a torch tensor on `device` holding the cloud on every rank."""
-    import torch
+def stats_rows(stats):
+    """list of binding.Stats -> (b, 4) float32 rows [iterations, status, pairs, mse]"""
+    return np.array([[s.iterations, s.status, s.final_pairs, s.final_mse] for s in stats], np.float32).reshape(-1, 4)
 
-    rank = dist.get_rank()
-    n = torch.tensor([0 if cloud is None else int(cloud.shape[1])], dtype=torch.int64, device=device)
-    dist.broadcast(n, src=src)
-    if rank == src:
-        t = torch.as_tensor(np.ascontiguousarray(cloud, np.float32)).to(device)
+
+class TorchComm:
+    """The collectives over torch.distributed (host or device tensors on `device`)."""
+
+    kind = "torch.distributed"
+
+    def __init__(self, dist, device):
+        self.dist, self.device = dist, device
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.kind = f"torch.distributed({dist.get_backend()})"
+
+    def broadcast_cloud(self, cloud, src=0):
+        """(3, N) float32 cloud from rank `src` (others pass None) -> torch tensor on every rank."""
+        import torch
+
+        n = torch.tensor([0 if cloud is None else int(cloud.shape[1])], dtype=torch.int64, device=self.device)
+        self.dist.broadcast(n, src=src)
+        if self.rank == src:
+            t = torch.as_tensor(np.ascontiguousarray(cloud, np.float32)).to(self.device)
+        else:
+            t = torch.empty((3, int(n.item())), dtype=torch.float32, device=self.device)
+        self.dist.broadcast(t, src=src)
+        return t
+
+    def gather_results(self, T_local, S_local, n_total):
+        """T_local (b, 4, 4), S_local (b, 4) of this rank's block -> (n_total, 4, 4), (n_total, 4)
+        in global pair order, identical on every rank."""
+        import torch
+
+        bmax = max(partition(n_total, self.world, r)[1] for r in range(self.world))
+        buf = torch.zeros((bmax, 20), dtype=torch.float32, device=self.device)
+        b = T_local.shape[0]
+        if b:
+            buf[:b, :16] = torch.as_tensor(np.ascontiguousarray(T_local, np.float32).reshape(b, 16)).to(self.device)
+            buf[:b, 16:] = torch.as_tensor(np.ascontiguousarray(S_local, np.float32)).to(self.device)
+        out = [torch.empty_like(buf) for _ in range(self.world)]
+        self.dist.all_gather(out, buf)
+        T = np.zeros((n_total, 4, 4), np.float32)
+        S = np.zeros((n_total, 4), np.float32)
+        for r in range(self.world):
+            s, c = partition(n_total, self.world, r)
+            a = out[r][:c].cpu().numpy()
+            T[s:s + c] = a[:, :16].reshape(c, 4, 4)
+            S[s:s + c] = a[:, 16:]
+        return T, S
+
+    def allreduce_sums(self, sums, count):
+        import torch
+
+        buf = torch.zeros(len(sums) + 1, dtype=torch.float64, device=self.device)
+        buf[:-1] = torch.as_tensor(np.asarray(sums, np.float64))
+        buf[-1] = float(count)
+        self.dist.all_reduce(buf, op=self.dist.ReduceOp.SUM)
+        out = buf.cpu().numpy()
+        return out[:-1].copy(), int(round(out[-1]))
+
+    def barrier(self):
+        self.dist.barrier()
+
+
+class RcclComm:
+    """The C ABI's RCCL communicator on a binding.Context.  `exchange(id_or_None)` must return
+    rank 0's 128-byte id on every rank (any side channel: torch store, MPI, a file)."""
+
+    kind = "icpk_comm (RCCL behind the C ABI)"
+
+    def __init__(self, ctx, rank, world, exchange):
+        from . import binding
+
+        self.ctx, self.rank, self.world = ctx, rank, world
+        uid = exchange(binding.comm_unique_id() if rank == 0 else None)
+        ctx.comm_init(uid, rank, world)
+
+    def broadcast_target(self, root=0):
+        """the root context's target cloud becomes the target of every rank's context"""
+        self.ctx.comm_broadcast_target(root)
+
+    def gather_results(self, T_local, stats_local, n_total):
+        return self.ctx.comm_gather_results(T_local, stats_local, n_total)
+
+    def allreduce_sums(self, sums, count):
+        return self.ctx.comm_allreduce_sums(sums, count)
+
+    def barrier(self):
+        self.ctx.comm_barrier()
+
+    def close(self):
+        self.ctx.comm_destroy()
+
+
+# ---- frame-batch mode -------------------------------------------------------------------
+def align_pair_batch(n_pairs, make_pair, align_batch_fn, comm):
+    """BASELINE config 4: n_pairs independent frame pairs, block-partitioned over the ranks.
+    make_pair(i) -> (source (3, Ns), target (3, Nt)) of global pair i (called for this rank's
+    pairs only); align_batch_fn(list_of_pairs) -> (T (b, 4, 4), S (b, 4) rows
+    [iterations, status, pairs, mse]) -- on a GPU: Context.align_batch + stats_rows.
+    Returns the gathered (T, S) of all pairs, identical on every rank."""
+    start, count = partition(n_pairs, comm.world, comm.rank)
+    pairs = [make_pair(start + k) for k in range(count)]
+    if count:
+        T_local, S_local = align_batch_fn(pairs)
     else:
-        t = torch.empty((3, int(n.item())), dtype=torch.float32, device=device)
-    dist.broadcast(t, src=src)
-    return t
+        T_local, S_local = np.zeros((0, 4, 4), np.float32), np.zeros((0, 4), np.float32)
+    return comm.gather_results(np.asarray(T_local, np.float32), np.asarray(S_local, np.float32), n_pairs)
+
+
+# torch.distributed spellings kept for callers that hold a process group
+def broadcast_cloud(cloud, src, device, dist):
+    return TorchComm(dist, device).broadcast_cloud(cloud, src)
 
 
 def gather_results(T_local, stats_local, n_total, device, dist):
-    """All-gather per-rank results into global frame order.
-    T_local: (b, 4, 4) float32, stats_local: (b, 4) float32 [iterations, status,
-    pairs, mse].  Returns (n_total,4,4) and (n_total,4) numpy arrays on every rank."""
-    import torch
-
-    world, rank = dist.get_world_size(), dist.get_rank()
-    bmax = max(partition(n_total, world, r)[1] for r in range(world))
-    buf = torch.zeros((bmax, 20), dtype=torch.float32, device=device)
-    b = T_local.shape[0]
-    if b:
-        buf[:b, :16] = torch.as_tensor(np.ascontiguousarray(T_local, np.float32).reshape(b, 16)).to(device)
-        buf[:b, 16:] = torch.as_tensor(np.ascontiguousarray(stats_local, np.float32)).to(device)
-    out = [torch.empty_like(buf) for _ in range(world)]
-    dist.all_gather(out, buf)
-    T = np.zeros((n_total, 4, 4), np.float32)
-    S = np.zeros((n_total, 4), np.float32)
-    for r in range(world):
-        s, c = partition(n_total, world, r)
-        a = out[r][:c].cpu().numpy()
-        T[s:s + c] = a[:, :16].reshape(c, 4, 4)
-        S[s:s + c] = a[:, 16:]
-    return T, S
+    return TorchComm(dist, device).gather_results(T_local, stats_local, n_total)
 
 
 def align_frame_batch(make_source, n_frames, target_on_rank0, align_fn, device, dist):
-    """Aligns n_frames source frames against one shared target.
-    make_source(i) -> (3, N) float32 source cloud of global frame i (only called for
-    this rank's frames); target_on_rank0: (3, Nt) cloud on rank 0, None elsewhere;
+    """Scan-to-key-frame variant: n_frames source frames against ONE target broadcast from rank 0.
+    make_source(i) -> (3, N) source of global frame i (this rank's frames only);
     align_fn(source_np, target_tensor) -> (T (4,4), iterations, status, pairs, mse).
     Returns the gathered (T, stats) for all frames, identical on every rank."""
-    world, rank = dist.get_world_size(), dist.get_rank()
-    tgt = broadcast_cloud(target_on_rank0, 0, device, dist)
-    start, count = partition(n_frames, world, rank)
+    comm = TorchComm(dist, device)
+    tgt = comm.broadcast_cloud(target_on_rank0, 0)
+    start, count = partition(n_frames, comm.world, comm.rank)
     T_local = np.zeros((count, 4, 4), np.float32)
     S_local = np.zeros((count, 4), np.float32)
     for k in range(count):
         T, it, status, pairs, mse = align_fn(make_source(start + k), tgt)
         T_local[k] = T
         S_local[k] = (it, status, pairs, mse)
-    return gather_results(T_local, S_local, n_frames, device, dist)
+    return comm.gather_results(T_local, S_local, n_frames)
 
 
 # ---------------------------------------------------------------------------------------
@@ -122,24 +205,22 @@ def _inv3f(R):
                      (d * h - e * g) * s, (b * g - a * h) * s, (a * e - b * d) * s]).astype(np.float32).reshape(3, 3)
 
 
-def align_query_sharded(steps, dist, device, max_iterations=16, threshold=1e-4, max_nn_dist=0.75, min_pairs=3,
-                        solve=1, fixed_iterations=False):
+def align_query_sharded(steps, comm, device=None, max_iterations=16, threshold=1e-4, max_nn_dist=0.75, min_pairs=3,
+                        solve=1, fixed_iterations=False, last_rotation=None, last_translation=None):
     """Runs the ICP loop on this rank's slice of the queries (already uploaded as the
     source of `steps`, target already set on every rank).  solve: 0 reference flavour
-    (icp.cpp:199-246), 1 Kabsch (rigid_transform_3D.py).  Returns (T (4,4) float32,
-    iterations, total pairs, mse) -- identical on every rank."""
-    import torch
-
+    (icp.cpp:199-246), 1 Kabsch (rigid_transform_3D.py).  comm: RcclComm / TorchComm (or a
+    torch.distributed module together with `device`).
+    Returns (T (4,4) float32, iterations, total pairs, mse, status) -- identical on every rank;
+    status as icpk_align: 0, or W_TOO_FEW_PAIRS (1) after the fallback of icp.cpp:163-182."""
     from . import binding
+
+    if not hasattr(comm, "allreduce_sums"):  # a torch.distributed module
+        comm = TorchComm(comm, device)
 
     def global_sums():
         sums, cnt = steps.reduce(max_nn_dist)
-        buf = torch.zeros(20, dtype=torch.float64, device=device)
-        buf[:19] = torch.as_tensor(sums)
-        buf[19] = float(cnt)
-        dist.all_reduce(buf, op=dist.ReduceOp.SUM)  # RCCL all-reduce: 160 bytes per iteration
-        out = buf.cpu().numpy()
-        return out[:19], int(round(out[19]))
+        return comm.allreduce_sums(sums, cnt)  # 160 bytes per iteration
 
     def mse_of(sums, n):
         if n <= 0:
@@ -153,9 +234,17 @@ def align_query_sharded(steps, dist, device, max_iterations=16, threshold=1e-4, 
     Trot = np.eye(3, dtype=np.float32)
     offset = np.zeros(3, np.float32)
     Tk = np.eye(4)[:3].copy()
+    status = binding.OK
     i = 0
     while (fixed_iterations or mse > np.float32(threshold)) and i < max_iterations:
         if n < min_pairs:
+            # icp.cpp:163-182: fewer than 3 associations -- every rank re-applies the caller's
+            # last motion to its queries and the loop ends (same as icpk_align's fallback)
+            lr = np.eye(3, dtype=np.float32) if last_rotation is None else np.asarray(last_rotation, np.float32).reshape(3, 3)
+            lt = np.zeros(3, np.float32) if last_translation is None else np.asarray(last_translation, np.float32).reshape(3)
+            steps.transform(lr, lt)
+            offset = (-lt).astype(np.float32)
+            status = binding.W_TOO_FEW_PAIRS
             break
         if solve == 0:
             R = binding.solve_reference(sums[:9].astype(np.float32).reshape(3, 3))
@@ -179,4 +268,4 @@ def align_query_sharded(steps, dist, device, max_iterations=16, threshold=1e-4, 
         T[:3, 3] = offset
     else:
         T[:3, :] = Tk.astype(np.float32)
-    return T, i, n, mse
+    return T, i, n, mse, status

@@ -14,7 +14,8 @@ LIB_PATH = os.path.join(HERE, "lib", "libicpk.so")
 
 OK = 0
 W_TOO_FEW_PAIRS = 1
-E_ARG, E_EMPTY_TARGET, E_HIP, E_NOT_SET, E_NO_DEVICE = -1, -2, -3, -4, -5
+E_ARG, E_EMPTY_TARGET, E_HIP, E_NOT_SET, E_NO_DEVICE, E_RCCL = -1, -2, -3, -4, -5, -6
+COMM_ID_BYTES = 128
 SOLVE_REFERENCE, SOLVE_KABSCH, SOLVE_POINT_TO_PLANE = 0, 1, 2
 W_DEGENERATE = 2
 NORMALS_CROSS, NORMALS_REFERENCE = 0, 1
@@ -32,6 +33,9 @@ SYMBOLS = [
     "icpk_align_batch", "icpk_align_batch_device", "icpk_backproject", "icpk_backproject_with_normals", "icpk_set_target_normals",
     "icpk_get_target_normals", "icpk_reduce_p2l", "icpk_solve_point_to_plane", "icpk_pair_distance", "icpk_pair_distance3", "icpk_distance3", "icpk_make_rotation_matrix",
     "icpk_matrix_to_quaternion", "icpk_quaternion_to_euler", "icpk_solve_reference", "icpk_solve_kabsch",
+    "icpk_comm_unique_id", "icpk_comm_init_rccl", "icpk_comm_destroy", "icpk_comm_rank", "icpk_comm_world",
+    "icpk_comm_partition", "icpk_comm_broadcast_target", "icpk_comm_gather_results", "icpk_comm_allreduce_sums",
+    "icpk_comm_barrier",
 ]
 
 
@@ -151,8 +155,34 @@ def load():
     dp = C.POINTER(C.c_double)
     lib.icpk_solve_kabsch.argtypes = [C.c_int64, dp, dp, dp, dp, dp]
     lib.icpk_solve_kabsch.restype = None
+    lib.icpk_comm_unique_id.argtypes = [C.c_void_p]
+    lib.icpk_comm_init_rccl.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    lib.icpk_comm_destroy.argtypes = [C.c_void_p]
+    lib.icpk_comm_rank.argtypes = [C.c_void_p]
+    lib.icpk_comm_world.argtypes = [C.c_void_p]
+    lib.icpk_comm_partition.argtypes = [C.c_int32, C.c_int, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    lib.icpk_comm_partition.restype = None
+    lib.icpk_comm_broadcast_target.argtypes = [C.c_void_p, C.c_int]
+    lib.icpk_comm_gather_results.argtypes = [C.c_void_p, fp, C.POINTER(Stats), C.c_int32, C.c_int32, fp, fp]
+    lib.icpk_comm_allreduce_sums.argtypes = [C.c_void_p, dp, C.c_int32, C.POINTER(C.c_int64)]
+    lib.icpk_comm_barrier.argtypes = [C.c_void_p]
     _lib = lib
     return lib
+
+
+def comm_unique_id():
+    """ncclGetUniqueId through the C ABI: 128 opaque bytes rank 0 ships to the other ranks."""
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    rc = load().icpk_comm_unique_id(buf)
+    if rc != OK:
+        raise IcpkError(rc, "icpk_comm_unique_id failed (librccl.so.1 not loadable?)")
+    return buf.raw
+
+
+def comm_partition(n_items, world, rank):
+    s, c = C.c_int32(0), C.c_int32(0)
+    load().icpk_comm_partition(n_items, world, rank, C.byref(s), C.byref(c))
+    return s.value, c.value
 
 
 def _f(a):
@@ -447,6 +477,52 @@ class Context:
         st = (Stats * max(n, 1))()
         rc = self._lib.icpk_align_batch_device(self._h, n, arr, C.byref(p), _fp(T), st)
         return T[:n].reshape(n, 4, 4), list(st)[:n], rc
+
+    # -- RCCL collectives behind the C ABI (icpk_comm.cpp) -------------------------------
+    def comm_init(self, unique_id, rank, world):
+        buf = C.create_string_buffer(bytes(unique_id), COMM_ID_BYTES)
+        self._chk(self._lib.icpk_comm_init_rccl(self._h, buf, rank, world))
+
+    def comm_destroy(self):
+        self._chk(self._lib.icpk_comm_destroy(self._h))
+
+    @property
+    def comm_rank(self):
+        return self._lib.icpk_comm_rank(self._h)
+
+    @property
+    def comm_world(self):
+        return self._lib.icpk_comm_world(self._h)
+
+    def comm_broadcast_target(self, root=0):
+        self._chk(self._lib.icpk_comm_broadcast_target(self._h, root))
+
+    def comm_gather_results(self, T_local, stats_local, n_total):
+        """T_local (b, 4, 4) float32 and the list of Stats of this rank's block -> (T (n_total, 4, 4),
+        S (n_total, 4) = iterations, status, pairs, mse), identical on every rank."""
+        T_local = np.ascontiguousarray(T_local, np.float32).reshape(-1, 16)
+        b = T_local.shape[0]
+        st = (Stats * max(b, 1))()
+        for k in range(b):
+            if isinstance(stats_local[k], Stats):
+                st[k] = stats_local[k]
+            else:  # a row [iterations, status, pairs, mse] (batch.stats_rows)
+                it, status, pairs, mse = stats_local[k]
+                st[k].iterations, st[k].status, st[k].final_pairs, st[k].final_mse = int(it), int(status), int(pairs), float(mse)
+        T = np.zeros((max(n_total, 1), 16), np.float32)
+        S = np.zeros((max(n_total, 1), 4), np.float32)
+        self._chk(self._lib.icpk_comm_gather_results(self._h, _fp(T_local) if b else None, st, b, n_total, _fp(T), _fp(S)))
+        return T[:n_total].reshape(n_total, 4, 4), S[:n_total]
+
+    def comm_allreduce_sums(self, sums, count):
+        sums = np.ascontiguousarray(sums, np.float64).copy()
+        cnt = C.c_int64(int(count))
+        self._chk(self._lib.icpk_comm_allreduce_sums(self._h, sums.ctypes.data_as(C.POINTER(C.c_double)), sums.size,
+                                                     C.byref(cnt)))
+        return sums, cnt.value
+
+    def comm_barrier(self):
+        self._chk(self._lib.icpk_comm_barrier(self._h))
 
     def set_log_callback(self, fn):
         """fn(key, quantity, usec) -- same shape as logDeltaTime (SLAM.hpp:30)."""

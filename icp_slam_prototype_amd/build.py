@@ -10,7 +10,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libicpk.so")
 
-SOURCES = ["icpk_api.cpp", "kernels_nn.hip", "kernels_reduce.hip", "kernels_transform.hip",
+SOURCES = ["icpk_api.cpp", "icpk_comm.cpp", "kernels_nn.hip", "kernels_reduce.hip", "kernels_transform.hip",
            "kernels_backproject.hip", "kernels_sort.hip", "kernels_nn_pruned.hip", "kernels_loop.hip", "kernels_grid.hip"]
 
 # -ffp-contract=off: the exact kernels spell out every fma they want; nothing may
@@ -39,7 +39,7 @@ def build(force=False, verbose=False, extra=(), out=None):
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)
         objs.append(o)
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out or LIB] + objs
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out or LIB] + objs + ["-ldl"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

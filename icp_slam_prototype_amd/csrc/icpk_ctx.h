@@ -1,0 +1,142 @@
+// icpk_ctx.h -- the context object behind the opaque icpk_ctx of include/icpk.h, shared by
+// the host-side translation units (icpk_api.cpp, icpk_comm.cpp).  Not part of the ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <string>
+#include <vector>
+
+#include "icpk.h"
+#include "icpk_internal.h"
+
+namespace icpk {
+
+struct Cloud {
+  float* base = nullptr;
+  int n = 0;
+  int cap = 0;  // floats per plane, multiple of NN_TILE
+  float* x() const { return base; }
+  float* y() const { return base + cap; }
+  float* z() const { return base + 2 * (size_t)cap; }
+};
+
+inline int round_up(int v, int m) { return ((v + m - 1) / m) * m; }
+
+}  // namespace icpk
+
+using icpk::nn_key_t;
+using icpk::LoopState;
+using icpk::GridInfo;
+using icpk::NSUM;
+
+struct icpk_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  icpk::Cloud tgt, src0, src;
+  icpk::Cloud nrm;  // target normals (point-to-plane), same indexing as tgt
+  bool have_normals = false;
+  icpk::Cloud dec;  // every NN_SEED_STRIDE-th target (seeding pre-pass of the filtered NN)
+  bool have_tgt = false, have_src = false, have_assoc = false;
+  bool have_dec = false;   // dec matches tgt
+  bool have_boxes = false; // boxes match tgt
+  float* boxes = nullptr;  // [6][tbox_stride] tile boxes then [6][sbox_stride] sub-tile boxes
+  int boxes_tiles_cap = 0;
+  // pruned scan: Morton-ordered copy of the target, its permutation, the query order
+  icpk::Cloud sorted;
+  int* tperm = nullptr;
+  unsigned* tkeys = nullptr;  // sorted Morton codes of the target (first-sweep seeding)
+  int tperm_cap = 0;
+  int* qperm = nullptr;
+  int qperm_cap = 0;
+  bool have_qperm = false;
+  float* bounds = nullptr;  // 6 floats: lo xyz, hi xyz of the target
+  unsigned* sort_keys = nullptr;  // 2 x sort_cap
+  int* sort_vals = nullptr;       // sort_cap
+  int sort_cap = 0;
+  void* sort_temp = nullptr;
+  size_t sort_temp_bytes = 0;
+  bool have_seed = false;  // `best` holds matches of a previous sweep of the same clouds
+  nn_key_t* best = nullptr;
+  nn_key_t* seed = nullptr;
+  nn_key_t* best_m = nullptr;  // pruned scan: results / seeds in query Morton order
+  nn_key_t* seed_m = nullptr;
+  bool have_seed_m = false;    // best_m holds the matches of the previous sweep under the current qperm
+  int32_t* idx = nullptr;
+  float* dist = nullptr;
+  int assoc_cap = 0;
+  double* partial = nullptr;
+  int* pcount = nullptr;
+  double* red_out = nullptr;   // device, 20 x 8 bytes
+  double* red_host = nullptr;  // pinned, 20 x 8 bytes
+  LoopState* st_dev = nullptr;   // device-side loop state
+  LoopState* st_host = nullptr;  // pinned staging copy
+  const int* stop = nullptr;     // &st_dev->done while a device loop is being enqueued, else null
+  LoopState* st_active = nullptr;  // st_dev while a device loop is being enqueued, else null
+  uint16_t* depth_dev = nullptr;
+  int depth_cap = 0;
+  int* bp_counts = nullptr;
+  int bp_counts_cap = 0;
+  int* bp_n_host = nullptr;  // pinned
+  std::vector<hipEvent_t> events;
+  std::vector<float> trace_R, trace_t, trace_mse;  // per-iteration record of the last align
+  std::vector<int32_t> trace_pairs;
+  int target_blocks = 16384;
+  int q_per_lane = 0;  // 0 = auto
+  int slices = 0;      // pruned scan: lanes per query (0 = by cloud size)
+  // grid scan (ICPK_NN_GRID): cell table + AoS copy of the target sorted by cell
+  icpk::GridInfo* grid_info = nullptr;
+  float* grid_bounds = nullptr;
+  int* cell_start = nullptr;  // GRID_MAX_CELLS + 1
+  float4* t4 = nullptr;
+  float4* qm4 = nullptr;     // queries in scan order (x, y, z, original index)
+  float4* sp_in = nullptr;   // seeds as points, scan order: read by the next grid sweep
+  float4* sp_out = nullptr;  // ... written by it
+  int qm4_cap = 0;
+  GridInfo grid_host{};      // host copy of *grid_info (read back once per target)
+  GridInfo* grid_host_pin = nullptr;  // pinned landing buffer of that read-back (truly asynchronous copy)
+  bool grid_phase1 = false;  // bounds / info of the current target are enqueued, read-back in flight
+  // frame-batch mode: child contexts (one per pair in flight; own stream for set-up work) --
+  // owned by the parent, never handed out
+  std::vector<icpk_ctx*> slots;
+  hipEvent_t ready_ev = nullptr;       // slot: set-up of the current pair is enqueued up to here
+  hipEvent_t group_ev[2] = {nullptr, nullptr};  // parent: the lock-step loop of a slot set has finished
+  int batch_group = 8;                 // pairs advancing in lock step (ICPK_BATCH_GROUP, <= BATCH_MAX)
+  std::vector<nn_key_t*> best_of_sweep;  // device loop: which buffer each enqueued sweep wrote
+  // RCCL communicator of the frame-batch / query-sharded modes (icpk_comm.cpp); null until
+  // icpk_comm_init_rccl
+  struct icpk_comm_state* comm = nullptr;
+  int* qcount = nullptr;     // query counting sort by cell: counts and starts, GRID_MAX_CELLS + 1 each
+  int* qstart = nullptr;
+  void* scan_temp = nullptr;
+  size_t scan_temp_bytes = 0;
+  int loop_nact = icpk::NSUM;      // device loop: sums the running alignment's step consumes (NSUM_REF or NSUM)
+  int profile_phase = 0;     // alignments profiled so far (offsets the sampled launches, see profile_stride)
+  int qperm_kind = 0;        // what qperm holds: 1 Morton order (pruned scan), 2 cell order (grid scan)
+  bool grid_chain = false;   // device loop only: the previous sweep was a grid sweep (qm4 / sp_in current)
+  int t4_cap = 0;
+  bool have_grid = false;  // grid matches tgt
+  float grid_ppc = 6.f;    // aimed-at targets per occupied cell (measured best on config 2: 6)
+  int grid_slices = 0;     // lanes per query (0 = by cloud size)
+  std::string err;
+  icpk_log_fn log_fn = nullptr;
+  void* log_user = nullptr;
+  std::chrono::steady_clock::time_point log_last;
+};
+
+#define ICPK_HIP(ctx, call)                                                                      \
+  do {                                                                                           \
+    hipError_t e__ = (call);                                                                     \
+    if (e__ != hipSuccess) {                                                                     \
+      (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e__);                           \
+      return ICPK_E_HIP;                                                                         \
+    }                                                                                            \
+  } while (0)
+
+// helpers of icpk_api.cpp that icpk_comm.cpp needs
+int icpk_host_fail(icpk_ctx* ctx, int code, const char* msg);
+int icpk_host_ensure_cloud(icpk_ctx* ctx, icpk::Cloud& c, int n);
+// the target cloud of ctx has been replaced on the device (n points, planes filled up to n):
+// pad it and drop everything derived from the previous target
+int icpk_host_target_replaced(icpk_ctx* ctx);
+void icpk_comm_release(icpk_ctx* ctx);  // called by icpk_destroy

@@ -41,6 +41,7 @@ extern "C" {
 #define ICPK_E_HIP (-3)          /* a HIP runtime call failed (see last_error)  */
 #define ICPK_E_NOT_SET (-4)      /* source or target not uploaded yet           */
 #define ICPK_E_NO_DEVICE (-5)    /* no usable HIP device: no CPU fallback       */
+#define ICPK_E_RCCL (-6)         /* librccl missing or an RCCL call failed       */
 
 /* ---- reference constants (defaults of icpk_default_params) --------------- */
 #define ICPK_MAX_NN_DISTANCE 0.75f          /* icp.hpp:8  MAX_NN_COLOR_DISTANCE    */
@@ -224,6 +225,35 @@ int icpk_align_batch(icpk_ctx *ctx, int32_t n_pairs, const icpk_pair *pairs,
  * device-to-device into the slots, so the caller's buffers stay untouched) */
 int icpk_align_batch_device(icpk_ctx *ctx, int32_t n_pairs, const icpk_pair *pairs,
                             const icpk_params *p, float *T_out, icpk_stats *stats);
+
+/* ---- multi-GPU: RCCL over xGMI behind the C ABI ------- */
+/* One process (or host thread) and one context per GPU.  The path shards over independent
+ * frame pairs (frame-pair formulation of icp.cpp:541-563): no per-iteration collective; the
+ * collectives are one broadcast of a shared target cloud (key frame) and one all-gather of the
+ * results.  librccl.so.1 is opened on first use (dlopen), not linked. */
+#define ICPK_COMM_ID_BYTES 128
+/* rank 0 makes the id (ncclGetUniqueId) and ships it to the other ranks by the host's own
+ * means (socket, file, MPI, torch store) */
+int icpk_comm_unique_id(void *id_out /* ICPK_COMM_ID_BYTES */);
+int icpk_comm_init_rccl(icpk_ctx *ctx, const void *unique_id, int rank, int world);
+int icpk_comm_destroy(icpk_ctx *ctx);
+int icpk_comm_rank(const icpk_ctx *ctx);   /* -1 without a communicator */
+int icpk_comm_world(const icpk_ctx *ctx);  /*  0 without a communicator */
+/* block-wise shard of n_items over world ranks: rank's contiguous [start, start + count) */
+void icpk_comm_partition(int32_t n_items, int world, int rank, int32_t *start, int32_t *count);
+/* the root's target cloud (icpk_set_target* / icpk_backproject there) becomes the target of
+ * every rank: ncclBroadcast of the three planes, 3 * Nt * 4 bytes */
+int icpk_comm_broadcast_target(icpk_ctx *ctx, int root);
+/* results of a block-partitioned batch of n_total pairs: this rank contributes the n_local
+ * rows of its block (T_local n_local x 16, stats_local n_local or NULL) and receives all rows
+ * in global pair order: T_all n_total x 16, stats_all n_total x 4 floats (iterations, status,
+ * final_pairs, final_mse) or NULL.  One ncclAllGather. */
+int icpk_comm_gather_results(icpk_ctx *ctx, const float *T_local, const icpk_stats *stats_local,
+                             int32_t n_local, int32_t n_total, float *T_all, float *stats_all);
+/* query-sharded single pair (SURVEY.md 8e alternative): sums[0..n) and *count summed over the
+ * ranks in place; one ncclAllReduce of (n + 1) doubles per iteration */
+int icpk_comm_allreduce_sums(icpk_ctx *ctx, double *sums, int32_t n, int64_t *count);
+int icpk_comm_barrier(icpk_ctx *ctx);
 
 /* ---- front end -------------------------------------- */
 /* pointcloud.cpp:19-58 without the rand()%40 subsample: row-major back-

@@ -13,6 +13,15 @@ from icp_slam_prototype_amd import binding, synth
 pytestmark = pytest.mark.gpu
 
 
+def _same_T(T, oT, tol=1e-6):
+    """north_star: transform within 1e-5 Frobenius of the reference arithmetic; asserted ten
+    times tighter.  (Until round 2 the product and the oracle shared one Jacobi SVD and agreed
+    bit for bit; the product now takes the orthogonal polar factor by Newton's iteration --
+    the same rotation, differing from the oracle's Jacobi result by ~1e-15 absolute, which is
+    several ulps of a float entry near zero.)"""
+    return float(np.linalg.norm(np.asarray(T, np.float64) - np.asarray(oT, np.float64))) < tol
+
+
 @pytest.fixture(scope="module")
 def ctx():
     from icp_slam_prototype_amd import build
@@ -283,7 +292,7 @@ def test_align_threshold_exit_fallback_and_idempotence(ctx, oracle):
     lt = np.array([1, 2, 3], np.float32)
     T, st, rc, o = _align_both(ctx, oracle, far, p["target"], last_translation=lt)
     assert rc == binding.W_TOO_FEW_PAIRS and o["status"] == 1 and st.iterations == 0 and st.final_pairs == 2
-    assert np.array_equal(T, o["T"]) and np.array_equal(T[:3, 3], -lt)
+    assert _same_T(T, o["T"]) and np.array_equal(T[:3, 3], -lt)
     assert np.array_equal(ctx.get_source(), o["src_out"])
 
 
@@ -299,7 +308,7 @@ def test_align_batch_and_log_callback(ctx, oracle):
     assert rc == 0 and T.shape == (3, 4, 4)
     for b, (s, t) in enumerate(pairs):
         o = oracle.align(s, t, max_iterations=5, solve=1, sum_order=1, fixed_iterations=True, threads=4)
-        assert np.array_equal(T[b], o["T"]) and st[b].iterations == 5
+        assert _same_T(T[b], o["T"]) and st[b].iterations == 5
     keys = [k for k, _, _ in log]
     assert keys.count(0) == 3 * 6 and keys.count(6) == 3 * 5  # LOG_NEAREST_NEIGHBOR, LOG_SVD (SLAM.hpp:4,10)
     assert all(us >= 0 for _, _, us in log)
@@ -488,7 +497,7 @@ def test_align_filtered_matches_oracle(ctx, oracle, solve, mode):
     T, st, rc, o = _align_both(ctx, oracle, p["source"], p["target"], solve=solve, max_iterations=6,
                                fixed_iterations=1, nn_mode=mode)
     assert st.iterations == o["iterations"] == 6
-    assert np.array_equal(T, o["T"])  # bit-identical, not just within 1e-5
+    assert _same_T(T, o["T"])
     idx, dist = ctx.get_associations()
     assert np.array_equal(idx, o["idx"]) and np.array_equal(dist.view(np.uint32), o["dist"].view(np.uint32))
     assert np.array_equal(ctx.get_source().view(np.uint32), o["src_out"].view(np.uint32))
@@ -614,7 +623,7 @@ def test_align_point_to_plane_matches_oracle(ctx, oracle):
                          normals=nrm, max_nn_dist=0.3)
         assert rc == 0 and st.iterations == o["iterations"] == 10 and st.final_pairs == o["final_pairs"]
         assert np.linalg.norm(T.astype(np.float64) - o["T"].astype(np.float64)) < 1e-5
-        assert np.array_equal(T, o["T"])
+        assert _same_T(T, o["T"])
         idx, dist = ctx.get_associations()
         assert np.array_equal(idx, o["idx"]) and np.array_equal(ctx.get_source(), o["src_out"])
     Rt, tt = p["R_true"], p["t_true"]
@@ -742,7 +751,7 @@ def test_many_iterations_uses_host_loop_and_matches(ctx, oracle):
     ctx.set_source(p["source"])
     T, st, rc = ctx.align(max_iterations=300, threshold=0.0, solve=binding.SOLVE_KABSCH)
     o = oracle.align(p["source"], p["target"], max_iterations=300, threshold=0.0, solve=1, sum_order=1)
-    assert st.iterations == o["iterations"] and np.array_equal(T, o["T"])
+    assert st.iterations == o["iterations"] and _same_T(T, o["T"], 1e-5)  # 300 iterations accumulate
 
 
 # ------------------------------------------------------------------- fuzzing --
@@ -855,12 +864,12 @@ def test_golden_fixture_on_device(ctx):
     sums, _ = ctx.reduce(0.75)
     assert np.array_equal(sums, g["f2_sums"])
     T, st, _ = ctx.align(max_iterations=8, threshold=0.0, solve=binding.SOLVE_REFERENCE)
-    assert np.array_equal(T, g["f3_T"])
+    assert _same_T(T, g["f3_T"])
     tr = ctx.get_trace()
-    assert np.array_equal(np.stack([t["R"] for t in tr]), g["f3_R"])
-    assert np.array_equal(np.stack([t["t"] for t in tr]), g["f3_t"])
+    assert _same_T(np.stack([t["R"] for t in tr]), g["f3_R"])
+    assert _same_T(np.stack([t["t"] for t in tr]), g["f3_t"])
     T, st, _ = ctx.align(max_iterations=8, threshold=0.0, solve=binding.SOLVE_KABSCH)
-    assert np.array_equal(T, g["f3_kabsch_T"])
+    assert _same_T(T, g["f3_kabsch_T"])
     assert np.array_equal(binding.make_rotation_matrix(10, 20, 30), g["f5_rot_10_20_30"])
     assert np.array_equal(binding.quaternion_to_euler(binding.matrix_to_quaternion(g["f5_rot_10_20_30"])), g["f5_euler"])
 

@@ -26,8 +26,8 @@ def _worker(rank, world, port, solve, q):
     ctx = binding.Context(0)
     ctx.set_target(tgt)
     ctx.set_source(np.ascontiguousarray(p["source"][:, s:s + c]))
-    T, it, n, mse = batch.align_query_sharded(batch.ContextSteps(ctx), dist, torch.device("cpu"), max_iterations=8,
-                                              solve=solve, fixed_iterations=True)
+    T, it, n, mse, status = batch.align_query_sharded(batch.ContextSteps(ctx), dist, torch.device("cpu"),
+                                                      max_iterations=8, solve=solve, fixed_iterations=True)
     q.put((rank, T, it, n, float(mse)))
     dist.barrier()
     dist.destroy_process_group()
