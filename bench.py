@@ -5,26 +5,38 @@
   (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N
           --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...)
 
-Workload (BASELINE.json configs[1]): one synthetic 640x480 Kinect frame pair,
-30% valid pixels (~92k points per cloud), 20 fixed ICP iterations.  One "step"
-= one icpk_align call = 21 brute-force NN sweeps + 20 reduce/solve/transform
-iterations, clouds already resident in HBM.  metric = ICP iterations/s (whole
-job); NN Mpoints/s and Gpairs/s are reported alongside.
+N = 1 (BASELINE.json configs[1]): one synthetic 640x480 Kinect frame pair, 30 % valid pixels
+(~92k points per cloud), 20 fixed ICP iterations.  One "step" = one icpk_align call = 21 NN
+sweeps + 20 reduce / solve / transform iterations, clouds resident in HBM.  value = ICP
+iterations/s of that single pair; NN Mpoints/s and Gpairs/s are reported alongside.  The same
+line carries
+  roofline            the NN kernel that was timed against what can physically bind it: HBM bytes
+                      per launch from the PMC counters (profiles/hbm_traffic.json, written by
+                      tools/collect_counters.py from separate rocprofv3 --pmc passes) over the
+                      launch duration measured live with HIP events on the kernel's stream,
+                      vs 8 TB/s; plus the VALU-issue fraction from SQ_INSTS_VALU;
+  roofline_algorithmic the brute-force scan's operand bytes (Nq*Nt*12 + Nq*20)
+                      over the same duration -- a YARDSTICK, not traffic (the grid kernel
+                      returns the brute-force result without touching those bytes);
+  roofline_bruteforce the kernel that does evaluate every pair (K1b), both ways;
+  cpu_baseline        the oracle's CPU restatement, pinned OpenMP threads, median of 5;
+  frame_batch         BASELINE configs[3] on ONE GPU: 64 distinct config-2 pairs (seeds
+                      100..163) through icpk_align_batch_device -- the number the N > 1 lines
+                      scale against;
+  extra               the dense 307 200-point pair (the metric string's "307k-pt") and config 5
+                      (10^6 x 10^6 points, 50 iterations).
 
-N > 1 is the frame-batch mode: one process per GPU, every rank
-aligns its own source frame against a key frame (target cloud) that rank 0
-broadcasts once over RCCL/xGMI; no per-iteration collective; weak scaling.
-
-The JSON line also carries
-  roofline      -- the NN kernel against the 8 TB/s HBM roofline on ALGORITHMIC
-                   bytes (Nq*Nt*12 + Nq*12 + Nq*8 per launch),
-                   duration measured with HIP events on the kernel's own stream;
-  cpu_baseline  -- the oracle's CPU restatement (OpenMP, all host cores) timed
-                   on a bounded query sample of the same workload (rank 0, N=1).
+N > 1 (BASELINE.json configs[3], frame-batch mode): the SAME 64 pairs,
+block-partitioned 64/N per rank, one process per GPU, every rank aligns its block in lock-step
+groups on its GPU, no per-iteration collective; one RCCL all-gather of the results per step
+(icpk_comm_gather_results, RCCL behind the C ABI).  One step = the whole 64-pair batch; value =
+aggregate iterations/s; total work is fixed, so "scaling" is "strong".
 """
 import argparse
 import json
 import os
+import statistics
+import subprocess
 import sys
 import time
 
@@ -34,26 +46,38 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+N_SIMD = 256 * 4           # 256 CUs x 4 SIMDs
+VALU_ISSUE_PER_SIMD = 1.2e9  # wave64 fp32 VALU: one wave-instruction per 2 cycles at 2.4 GHz (MI355X_MICROARCH.md)
+METRIC = "ICP iterations/sec + NN Mpoints/sec at 307k-pt Kinect cloud, 1/2/4/8 GPU"
+DTYPE = "f32 filter + f64 exact pair arithmetic (reference float semantics), f64 reductions and solve"
+BATCH_PAIRS = 64           # BASELINE configs[3]
+BATCH_SEED0 = 100          # seeds 100..163
+KERNEL_NAMES = {"exact": "nn_exact_kernel", "filtered": "nn_filtered_kernel<2>", "pruned": "nn_pruned_kernel<4>",
+                "grid": "nn_grid_kernel<8,false|true>"}
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--iters", type=int, default=20, help="fixed ICP iterations per step (config 2: 20)")
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--iters", type=int, default=20, help="fixed ICP iterations per alignment (config 2: 20)")
     ap.add_argument("--workload", default="kinect640x480_30pct",
                     choices=["kinect640x480_30pct", "kinect640x480_dense", "kinect_v2_512x424", "dense1m", "frustum10k"])
     ap.add_argument("--solve", default="reference", choices=["reference", "kabsch", "p2l"])
     ap.add_argument("--nn-mode", default="grid", choices=["exact", "filtered", "pruned", "grid"],
                     help="all four give bit-identical results; grid is the product default")
     ap.add_argument("--shard", default="frames", choices=["frames", "queries"],
-                    help="N>1: 'frames' = one frame pair per rank, no per-iteration collective (default, weak "
-                         "scaling); 'queries' = ONE pair, queries split over ranks, one 160-byte all-reduce per "
-                         "iteration (strong scaling; SURVEY.md 8e alternative)")
+                    help="N>1: 'frames' = BASELINE config 4, 64 pairs block-partitioned over the ranks (default); "
+                         "'queries' = ONE pair, queries split over ranks, one 160-byte all-reduce per iteration "
+                         "(SURVEY.md 8e alternative)")
+    ap.add_argument("--comm", default="auto", choices=["auto", "icpk", "torch"],
+                    help="N>1 collectives: RCCL behind the C ABI (icpk_comm_*) or torch.distributed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=32768, help="queries in the CPU baseline sample")
+    ap.add_argument("--no-extras", action="store_true", help="skip the frame_batch / dense / config-5 blocks at N = 1")
+    ap.add_argument("--batch-pairs", type=int, default=BATCH_PAIRS)
+    ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
@@ -71,264 +95,484 @@ def make_workload(name, seed):
     return synth.frustum_pair(10000, seed=seed)
 
 
-def cpu_baseline(src, tgt, sample, solve):
-    """Oracle (CPU restatement, kind 'port') on the host cores: NN sweep over a
-    contiguous query sample against the full target, scaled linearly to Nq, plus
-    the reduce/solve/transform of one iteration measured on the full clouds."""
+# ------------------------------------------------------------------------- CPU baseline --
+def cpu_topology():
+    """Cores this process may really use: the cgroup CPU quota (a box with one GPU gets a
+    share of the host), the affinity mask and the socket size from lscpu."""
+    info = {"logical_cpus": os.cpu_count(), "affinity": len(os.sched_getaffinity(0)), "quota_cpus": None,
+            "model": None, "sockets": None, "cores_per_socket": None, "threads_per_core": None}
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            info["quota_cpus"] = float(q) / float(per)
+    except Exception:
+        pass
+    try:
+        for line in subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout.splitlines():
+            k, _, v = line.partition(":")
+            v = v.strip()
+            if k == "Model name":
+                info["model"] = v
+            elif k == "Socket(s)":
+                info["sockets"] = int(v)
+            elif k == "Core(s) per socket":
+                info["cores_per_socket"] = int(v)
+            elif k == "Thread(s) per core":
+                info["threads_per_core"] = int(v)
+    except Exception:
+        pass
+    return info
+
+
+def cpu_baseline(workload):
+    """The CPU baseline runs in a CHILD process (it never touches the GPU): libgomp binds the
+    calling thread when OMP_PROC_BIND is set, and the parent's host thread -- and the HIP
+    runtime's helper threads that inherit its mask -- must not end up pinned to one core."""
+    env = dict(os.environ, OMP_PROC_BIND="close", OMP_PLACES="cores")
+    env.pop("OMP_NUM_THREADS", None)
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", "--workload", workload],
+                       env=env, capture_output=True, text=True, timeout=600)
+    if r.returncode != 0:
+        return {"error": (r.stderr or r.stdout)[-400:]}
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+def cpu_baseline_child(workload):
+    """Oracle (CPU restatement, kind 'port'; gcc -O2 + OpenMP over queries) on the host cores
+    this box grants: threads = min(cgroup quota, cores of ONE socket), pinned (OMP_PROC_BIND=close,
+    OMP_PLACES=cores), warm-up, then the median of 5 samples of >= ~2 s each of the NN sweep over
+    a contiguous query sample against the full target, scaled linearly to Nq, plus the reduce /
+    solve / transform of one iteration on the full clouds; and the 1-thread cost per pair."""
+    topo = cpu_topology()  # before libgomp is loaded: it narrows this thread's affinity mask
+    w = make_workload(workload, 2)
+    src, tgt = np.ascontiguousarray(w["source"]), np.ascontiguousarray(w["target"])
     from oracle import icp_oracle as o
 
-    threads = o.max_threads()
-    nq = src.shape[1]
-    m = min(sample, nq)
-    sub = np.ascontiguousarray(src[:, :m])
-    o.nn_bruteforce(sub[:, :256], tgt, threads=threads)  # warm
-    t0 = time.perf_counter()
-    idx, dist = o.nn_bruteforce(sub, tgt, threads=threads)
-    t_nn = (time.perf_counter() - t0) * nq / m
+    limit = topo["affinity"]
+    if topo["quota_cpus"]:
+        limit = min(limit, int(topo["quota_cpus"]))
+    if topo["cores_per_socket"]:
+        limit = min(limit, topo["cores_per_socket"])
+    threads = max(1, limit)  # explicit num_threads(): omp_get_max_threads() is whatever an earlier library set
+    nq, nt = src.shape[1], tgt.shape[1]
+
+    def sweep(m, th):
+        sub = np.ascontiguousarray(src[:, :m])
+        t0 = time.perf_counter()
+        idx, dist = o.nn_bruteforce(sub, tgt, threads=th)
+        return time.perf_counter() - t0, idx, dist
+
+    # calibrate the sample so that one sample takes ~2.5 s
+    sweep(min(256, nq), threads)  # warm-up (thread team, caches)
+    t_cal, _, _ = sweep(min(2048, nq), threads)
+    m = int(min(nq, max(2048, 2048 * 2.5 / max(t_cal, 1e-4))))
+    samples = []
+    for _ in range(5):
+        t, idx, dist = sweep(m, threads)
+        samples.append(t * nq / m)
+    t_nn = statistics.median(samples)
+    # one thread: cost per pair of the scalar scan (BASELINE.md B1 stand-in)
+    t1_cal, _, _ = sweep(min(128, nq), 1)
+    m1 = int(min(nq, max(128, 128 * 2.0 / max(t1_cal, 1e-4))))
+    t1, _, _ = sweep(m1, 1)
+    ns_per_pair_1t = t1 / (float(m1) * nt) * 1e9
     idx_full = np.resize(idx, nq)
     dist_full = np.resize(dist, nq)
-    t0 = time.perf_counter()
-    sums, cnt = o.sums_canonical(src, tgt, idx_full, dist_full, 0.75)
-    M = sums[:9].astype(np.float32)
-    R = o.solve_reference(M)
-    o.transform_points(src, o.inv3(R), -(sums[9:12] / max(cnt, 1)).astype(np.float32))
-    t_rest = time.perf_counter() - t0
+    rest = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        sums, cnt = o.sums_canonical(src, tgt, idx_full, dist_full, 0.75)
+        R = o.solve_reference(sums[:9].astype(np.float32))
+        o.transform_points(src, o.inv3(R), -(sums[9:12] / max(cnt, 1)).astype(np.float32))
+        rest.append(time.perf_counter() - t0)
+    t_rest = statistics.median(rest)
     it_s = 1.0 / (t_nn + t_rest)
-    return {
+    spread = (max(samples) - min(samples)) / t_nn
+    out = {
         "value": it_s, "unit": "iter/s", "cores": threads, "kind": "port",
-        "sample": f"NN sweep of {m} of {nq} queries x {tgt.shape[1]} targets on {threads} OpenMP threads "
-                  f"(scaled linearly to Nq) + full reduce/solve/transform; oracle/icp_oracle.c, gcc -O2",
-        "nn_s_per_sweep": t_nn, "gpairs_per_s": nq * tgt.shape[1] / t_nn / 1e9,
+        "sample": f"median of 5 NN sweeps of {m} of {nq} queries x {nt} targets on {threads} pinned OpenMP threads "
+                  f"(OMP_PROC_BIND={os.environ.get('OMP_PROC_BIND')}, OMP_PLACES={os.environ.get('OMP_PLACES')}; "
+                  f"each sample {t_nn * m / nq:.1f} s, scaled linearly to Nq; spread {spread * 100:.1f} %) + median of 3 "
+                  f"full reduce/solve/transform; oracle/icp_oracle.c, gcc -O2",
+        "nn_s_per_sweep": t_nn, "gpairs_per_s": nq * float(nt) / t_nn / 1e9, "sample_spread": spread,
+        "one_thread_ns_per_pair": ns_per_pair_1t,
+        "host": {"model": topo["model"], "sockets": topo["sockets"], "cores_per_socket": topo["cores_per_socket"],
+                 "threads_per_core": topo["threads_per_core"], "logical_cpus": topo["logical_cpus"],
+                 "cgroup_cpu_quota": topo["quota_cpus"]},
     }
+    if topo["cores_per_socket"] and threads < topo["cores_per_socket"]:
+        # the box's CPU share is smaller than a socket: say what a whole socket would do if the
+        # scan scaled linearly (it is embarrassingly parallel over queries) -- an extrapolation
+        f = topo["cores_per_socket"] / threads
+        out["single_socket_extrapolated_iter_s"] = it_s * f
+        out["note"] = (f"this box grants {threads} CPUs (cgroup quota) of a {topo['sockets']} x {topo['cores_per_socket']}-core "
+                       f"host: the measured value is for {threads} cores; single_socket_extrapolated_iter_s = value x {f:.1f} "
+                       "assumes linear scaling to one whole socket and is NOT measured")
+    return out
 
 
-def main():
-    args = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+# --------------------------------------------------------------------------- PMC figures --
+def pmc_entry(workload, nn_mode):
+    """Per-launch counter figures of the NN kernel for this workload, written by
+    tools/collect_counters.py from separate rocprofv3 --pmc passes (None if never collected)."""
+    f = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if not os.path.exists(f):
+        return None
+    e = json.load(open(f)).get(f"{workload}:{nn_mode}")
+    return e if isinstance(e, dict) else None
 
-    import torch
 
-    from icp_slam_prototype_amd import binding
+def roofline_blocks(workload, nn_mode, nq, nt, avg_nn_s, timing, kernel):
+    alg_bytes = float(nq) * nt * 12 + nq * 12 + nq * 8  # SURVEY.md 8d
+    e = pmc_entry(workload, nn_mode)
+    phys = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+            "kernel": kernel, "avg_launch_ms": avg_nn_s * 1e3, "timing": timing}
+    if e:
+        traffic = float(e["hbm_bytes_per_launch"])
+        phys.update({
+            "achieved": traffic / avg_nn_s / 1e9, "frac": traffic / avg_nn_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
+            "traffic_source": "profiles/hbm_traffic.json <- tools/collect_counters.py: (2 x FETCH_SIZE + WRITE_SIZE) KB "
+                              "per NN launch from separate rocprofv3 --pmc passes (gfx950 FETCH_SIZE correction of "
+                              "MI355X_MICROARCH.md); raw CSVs under profiles/",
+            "compulsory_bytes": float(nq + nt) * 12 + nq * 8,
+        })
+        if e.get("valu_insts_per_launch"):
+            v = float(e["valu_insts_per_launch"])
+            phys["valu_insts_per_launch"] = v
+            phys["valu_issue_frac"] = v / (N_SIMD * VALU_ISSUE_PER_SIMD * avg_nn_s)
+            phys["valu_issue_note"] = ("SQ_INSTS_VALU per launch / (1024 SIMDs x 1.2 G wave-instructions/s x launch time): "
+                                       "the fp32 issue bound; f64 and sqrt instructions issue 2-4x slower, so the true "
+                                       "issue occupancy is higher")
+        phys["binds"] = e.get("binds", "neither roofline: per-wave latency / instruction issue")
+    yard = {"bound": "hbm", "achieved": alg_bytes / avg_nn_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": alg_bytes / avg_nn_s / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": alg_bytes,
+            "gpairs_per_s_kernel": nq * float(nt) / avg_nn_s / 1e9,
+            "note": "YARDSTICK, not traffic: operand bytes of the brute-force scan this kernel replaces "
+                    "(Nq*Nt*12 + Nq*20, SURVEY.md 8d) over the measured launch time; the grid / pruned kernels return "
+                    "the same result while only looking at targets within reach"}
+    return phys, yard
 
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
-    # Rehearsal on a 1-GPU box (never used by the driver): ICPK_BENCH_REHEARSAL=1 maps every
-    # rank to cuda:0 and runs the collectives over gloo, because RCCL refuses two ranks on
-    # one device.  The real multi-GPU run uses backend "nccl" (= RCCL over xGMI).
-    rehearsal = os.environ.get("ICPK_BENCH_REHEARSAL") == "1"
-    gpu_index = 0 if rehearsal else local_rank
-    torch.cuda.set_device(gpu_index)
-    dev = torch.device("cuda", gpu_index)
-    cdev = torch.device("cpu") if rehearsal else dev  # device of the tensors handed to collectives
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
 
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if rehearsal:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+# ------------------------------------------------------------------------------- helpers --
+def upload(torch, dev, a):
+    return torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev)
 
-    if args.shard == "queries" and world > 1:
-        return bench_query_sharded(args, rank, world, dev, cdev, gpu_index, dist)
 
-    # ---- workload: own source frame per rank; key frame (target) from rank 0 ----
-    base_seed = 2  # SURVEY.md 8d config 2
-    w = make_workload(args.workload, base_seed + 100 * rank if world > 1 else base_seed)
-    src_h = np.ascontiguousarray(w["source"])
-    src_d = torch.from_numpy(src_h).to(dev)
-    if world > 1:
-        from icp_slam_prototype_amd import batch
-
-        # RCCL broadcast of the key frame's xyz-SoA over xGMI (one 3*Nt*4-byte message)
-        tgt_d = batch.broadcast_cloud(w["target"] if rank == 0 else None, 0, cdev, dist).to(dev)
-        tgt_h = tgt_d.cpu().numpy()
-    else:
-        tgt_h = np.ascontiguousarray(w["target"])
-        tgt_d = torch.from_numpy(tgt_h).to(dev)
-    torch.cuda.synchronize()
-    nq, nt = src_d.shape[1], tgt_d.shape[1]
-
-    ctx = binding.Context(gpu_index)
+def set_clouds_device(ctx, src_d, tgt_d):
     es = src_d.element_size()
+    nq, nt = src_d.shape[1], tgt_d.shape[1]
     ctx.set_target_device(tgt_d.data_ptr(), tgt_d.data_ptr() + nt * es, tgt_d.data_ptr() + 2 * nt * es, nt)
     ctx.set_source_device(src_d.data_ptr(), src_d.data_ptr() + nq * es, src_d.data_ptr() + 2 * nq * es, nq)
 
-    if args.solve == "p2l":
-        # point-to-plane (config 3): the target and its normals come from the depth image
-        kw = dict(fx=float(w.get("fx", 468.60)), cx=float(w.get("cx", 318.27)))
-        ctx.backproject_with_normals(w["depth_tgt"], binding.NORMALS_CROSS, offset=[5, 5, 5], **kw)
-        assert ctx.target_size == nt
-    params = binding.default_params(
-        max_iterations=args.iters, fixed_iterations=1, profile=1,
-        max_nn_dist=0.3 if args.solve == "p2l" else 0.75,
-        solve={"reference": binding.SOLVE_REFERENCE, "kabsch": binding.SOLVE_KABSCH,
-               "p2l": binding.SOLVE_POINT_TO_PLANE}[args.solve],
-        nn_mode={"exact": binding.NN_EXACT, "filtered": binding.NN_FILTERED, "pruned": binding.NN_PRUNED, "grid": binding.NN_GRID}[args.nn_mode])
 
-    def sync_all():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
+def timed_alignments(torch, ctx, params, steps, warmup, sync_all):
+    """W untimed + exactly K timed icpk_align calls; every 21st NN launch (one per alignment, the
+    position rotating) is bracketed by two HIP events on the context's stream."""
+    params.profile = 0
+    for _ in range(warmup):
         ctx.align(params)
-    # per-stage device times from one extra, untimed alignment (events around every stage)
-    params.profile = 2
-    _, st2, _ = ctx.align(params)
-    stage_ms = {"nn": st2.nn_ms_total, "reduce": st2.reduce_ms_total, "transform": st2.transform_ms_total,
-                "total": st2.total_ms}
-    # timed region: every 7th K1 launch is bracketed by two HIP events, the offset rotating
-    # from alignment to alignment so that all 21 sweep positions are sampled evenly (an event
-    # pair costs ~4 us of queue time: ~10 % of an iteration if every launch carried one)
     params.profile = 1
-    params.profile_stride = 7
+    params.profile_stride = params.max_iterations + 1
     sync_all()
     t0 = time.perf_counter()
     nn_ms = 0.0
-    nn_launches = 0
-    nn_timed = 0
-    red_ms = tr_ms = 0.0
-    iters_done = 0
-    for _ in range(args.steps):
+    nn_timed = nn_launches = iters_done = 0
+    for _ in range(steps):
         T, st, rc = ctx.align(params)
         nn_ms += st.nn_ms_total
-        red_ms += st.reduce_ms_total
-        tr_ms += st.transform_ms_total
         nn_launches += st.nn_launches
         nn_timed += st.nn_timed_launches
         iters_done += st.iterations
     sync_all()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-        agg = torch.tensor([iters_done, nn_launches * nq, nn_launches * nq * nt], dtype=torch.float64, device=cdev)
-        dist.all_reduce(agg, op=dist.ReduceOp.SUM)
-        total_iters, total_queries, total_pairs = (float(v) for v in agg.tolist())
-    else:
-        total_iters, total_queries, total_pairs = float(iters_done), float(nn_launches * nq), float(nn_launches) * nq * nt
+    return elapsed, iters_done, nn_launches, nn_timed, nn_ms
 
-    if rank == 0:
-        avg_nn_s = nn_ms / max(nn_timed, 1) / 1e3
-        alg_bytes = float(nq) * nt * 12 + nq * 12 + nq * 8  # SURVEY.md 8d
-        achieved = alg_bytes / avg_nn_s / 1e9
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tfile):
-            traffic = json.load(open(tfile)).get(f"{args.workload}:{args.nn_mode}")
-        out = {
-            "metric": "ICP iterations/sec + NN Mpoints/sec at 307k-pt Kinect cloud, 1/2/4/8 GPU",
-            "value": total_iters / elapsed,
-            "unit": "iter/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f32 filter + f64 exact pair arithmetic (reference float semantics), f64 reductions",
-            "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {nq} source x {nt} target points, {args.iters} fixed ICP "
-                                   f"iterations per step, solve={args.solve}, nn={args.nn_mode}",
-                       "frame_pairs_per_step": world, "parallelism": f"frame-batch x{world}" if world > 1 else "1 GPU"},
-            "nn_mpoints_per_s": total_queries / elapsed / 1e6,
-            "nn_gpairs_per_s_wall": total_pairs / elapsed / 1e9,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": {"exact": "nn_exact_kernel", "filtered": "nn_filtered_kernel<2>",
-                                    "pruned": "nn_pruned_kernel<4>", "grid": "nn_grid_kernel<8,false|true>"}[args.nn_mode],
-                         "avg_launch_ms": avg_nn_s * 1e3, "algorithmic_bytes_per_launch": alg_bytes,
-                         "timing": f"two HIP events recorded on the kernel's own stream immediately around every 7th "
-                                   f"K1 launch of the timed region, the offset advancing with every alignment ({nn_timed} of "
-                                   f"{nn_launches} launches, first sweeps in proportion; includes "
-                                   "~5 us of dispatch latency per launch; the rocprofv3 --kernel-trace average of "
-                                   "the same command is in profiles/)",
-                         "gpairs_per_s_kernel": nq * nt / avg_nn_s / 1e9,
-                         "note": "algorithmic operand bytes of the brute-force scan this kernel replaces "
-                                 "(Nq*Nt*12 + Nq*20); the grid / pruned kernels return the same result while "
-                                 "only looking at targets within reach, so this is not physical traffic; see "
-                                 "roofline_bruteforce for the kernel that evaluates every pair"},
-            "stage_ms_per_step": stage_ms,
-        }
-        if world == 1 and args.nn_mode in ("pruned", "grid"):
-            # the same sweep by the brute-force (un-pruned) filtered kernel, for the roofline
-            # of the kernel north_star names: every one of the Nq*Nt pairs is evaluated
-            ctx.reset_source()
-            ctx.nn(binding.NN_FILTERED, fetch=False)  # seeds
-            reps = 5
-            torch.cuda.synchronize()
-            tb = time.perf_counter()
-            for _ in range(reps):
-                ctx.nn(binding.NN_FILTERED, fetch=False)
-            t_bf = (time.perf_counter() - tb) / reps
-            out["roofline_bruteforce"] = {
-                "bound": "hbm", "kernel": "nn_filtered_kernel<2>", "achieved": alg_bytes / t_bf / 1e9,
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg_bytes / t_bf / 1e9 / HBM_PEAK_GBS,
-                "avg_launch_ms": t_bf * 1e3, "gpairs_per_s_kernel": nq * nt / t_bf / 1e9,
-                "timing": "host wall clock around icpk_nn (includes one launch + sync, ~2%)",
-                "traffic": (json.load(open(tfile)).get(f"{args.workload}:filtered") if os.path.exists(tfile) else None)}
-            ctx.reset_source()
-        if world == 1:
-            # PCIe-inclusive rate (never `value`): the boundary handed host buffers, so
-            # every step re-uploads both clouds (pageable memory) before aligning
-            reps = max(2, min(args.steps, 5))
-            params.profile = 0
-            t1 = time.perf_counter()
-            for _ in range(reps):
-                if args.solve == "p2l":  # the depth image crosses PCIe; cloud and normals are built on the device
-                    ctx.backproject_with_normals(w["depth_tgt"], binding.NORMALS_CROSS, offset=[5, 5, 5],
-                                                 fx=float(w["fx"]), cx=float(w["cx"]))
-                else:
-                    ctx.set_target(tgt_h)
-                ctx.set_source(src_h)
-                ctx.align(params)
-            out["pcie_inclusive_iter_s"] = reps * args.iters / (time.perf_counter() - t1)
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(src_h, tgt_h, args.cpu_sample, args.solve)
-            out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
-        print(json.dumps(out))
+
+def batch_pairs_on_device(torch, dev, indices):
+    from icp_slam_prototype_amd import synth
+
+    keep, args = [], []
+    for i in indices:
+        p = synth.kinect_pair(480, 640, valid=0.30, seed=BATCH_SEED0 + i)
+        s, t = upload(torch, dev, p["source"]), upload(torch, dev, p["target"])
+        keep.append((s, t))
+        args.append((s.data_ptr(), s.shape[1], t.data_ptr(), t.shape[1]))
+    torch.cuda.synchronize()
+    return keep, args
+
+
+# --------------------------------------------------------------------------------- N = 1 --
+def bench_single(args, torch, dev, gpu_index):
+    from icp_slam_prototype_amd import binding
+
+    w = make_workload(args.workload, 2)  # SURVEY.md 8d config 2: seed 2
+    src_h, tgt_h = np.ascontiguousarray(w["source"]), np.ascontiguousarray(w["target"])
+    src_d, tgt_d = upload(torch, dev, src_h), upload(torch, dev, tgt_h)
+    torch.cuda.synchronize()
+    nq, nt = src_d.shape[1], tgt_d.shape[1]
+    ctx = binding.Context(gpu_index)
+    set_clouds_device(ctx, src_d, tgt_d)
+    if args.solve == "p2l":
+        # point-to-plane (config 3): the target and its normals come from the depth image
+        ctx.backproject_with_normals(w["depth_tgt"], binding.NORMALS_CROSS, offset=[5, 5, 5],
+                                     fx=float(w.get("fx", 468.60)), cx=float(w.get("cx", 318.27)))
+        assert ctx.target_size == nt
+    solve = {"reference": binding.SOLVE_REFERENCE, "kabsch": binding.SOLVE_KABSCH, "p2l": binding.SOLVE_POINT_TO_PLANE}
+    modes = {"exact": binding.NN_EXACT, "filtered": binding.NN_FILTERED, "pruned": binding.NN_PRUNED, "grid": binding.NN_GRID}
+    params = binding.default_params(max_iterations=args.iters, fixed_iterations=1,
+                                    max_nn_dist=0.3 if args.solve == "p2l" else 0.75,
+                                    solve=solve[args.solve], nn_mode=modes[args.nn_mode])
+
+    def sync_all():
+        torch.cuda.synchronize()
+
+    elapsed, iters_done, nn_launches, nn_timed, nn_ms = timed_alignments(torch, ctx, params, args.steps, args.warmup, sync_all)
+    avg_nn_s = nn_ms / max(nn_timed, 1) / 1e3
+    timing = (f"two HIP events on the kernel's own stream around one K1 launch per alignment of the timed region, the "
+              f"position rotating over the {args.iters + 1} sweeps ({nn_timed} of {nn_launches} launches; includes ~4 us of "
+              "event/dispatch latency; the rocprofv3 --kernel-trace average of the same command is in profiles/)")
+    phys, yard = roofline_blocks(args.workload, args.nn_mode, nq, nt, avg_nn_s, timing, KERNEL_NAMES[args.nn_mode])
+    # per-stage device times from one extra, untimed alignment (events around every stage)
+    params.profile = 2
+    _, st2, _ = ctx.align(params)
+    stage_ms = {"nn": st2.nn_ms_total, "reduce": st2.reduce_ms_total, "transform": st2.transform_ms_total, "total": st2.total_ms}
+    params.profile = 0
+    out = {
+        "metric": METRIC, "value": iters_done / elapsed, "unit": "iter/s", "n_gpus": 1, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
+        "config": {"workload": f"{args.workload}: ONE frame pair, {nq} source x {nt} target points, {args.iters} fixed ICP "
+                               f"iterations per step, solve={args.solve}, nn={args.nn_mode} (BASELINE configs[1]); the "
+                               f"N > 1 lines run configs[3] (64 such pairs) and scale against frame_batch below",
+                   "frame_pairs_per_step": 1, "parallelism": "1 GPU"},
+        "nn_mpoints_per_s": nn_launches * nq / elapsed / 1e6,
+        "nn_gpairs_per_s_wall": float(nn_launches) * nq * nt / elapsed / 1e9,
+        "roofline": phys, "roofline_algorithmic": yard, "stage_ms_per_step": stage_ms,
+    }
+    if args.nn_mode in ("pruned", "grid"):
+        # the same sweep by the brute-force (un-pruned) filtered kernel north_star names: every one
+        # of the Nq*Nt pairs is evaluated; HIP events on the context's stream around each launch
+        ctx.reset_source()
+        ctx.nn(binding.NN_FILTERED, fetch=False)  # seeds
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
+        s = torch.cuda.ExternalStream(ctx.stream)
+        for a, b in ev:
+            a.record(s)
+            ctx.nn(binding.NN_FILTERED, fetch=False)
+            b.record(s)
+        torch.cuda.synchronize()
+        t_bf = statistics.median(a.elapsed_time(b) for a, b in ev) / 1e3
+        p_bf, y_bf = roofline_blocks(args.workload, "filtered", nq, nt, t_bf,
+                                     "HIP events on the context's stream around icpk_nn(FILTERED) (fill + kernel + "
+                                     "sync), median of 5", KERNEL_NAMES["filtered"])
+        p_bf["algorithmic"] = y_bf
+        out["roofline_bruteforce"] = p_bf
+        ctx.reset_source()
+    # PCIe-inclusive rate (never `value`): the boundary handed host buffers, so every step
+    # re-uploads both clouds (pageable memory) and rebuilds the grid before aligning
+    reps = 5
+    t1 = time.perf_counter()
+    for _ in range(reps):
+        if args.solve == "p2l":  # the depth image crosses PCIe; cloud and normals are built on the device
+            ctx.backproject_with_normals(w["depth_tgt"], binding.NORMALS_CROSS, offset=[5, 5, 5],
+                                         fx=float(w["fx"]), cx=float(w["cx"]))
+        else:
+            ctx.set_target(tgt_h)
+        ctx.set_source(src_h)
+        ctx.align(params)
+    out["pcie_inclusive_iter_s"] = reps * args.iters / (time.perf_counter() - t1)
     ctx.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+
+    if not args.no_extras and args.workload == "kinect640x480_30pct" and args.solve == "reference" and args.nn_mode == "grid":
+        out["frame_batch"] = frame_batch_one_gpu(args, torch, dev, gpu_index, out["value"])
+        out["extra"] = {}
+        for name, iters, steps in (("kinect640x480_dense", 20, 10), ("dense1m", 50, 4)):
+            out["extra"][f"{name}_{iters}iters"] = extra_workload(args, torch, dev, gpu_index, name, iters, steps)
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.workload)
+        if "value" in out["cpu_baseline"]:
+            out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+        if "single_socket_extrapolated_iter_s" in out["cpu_baseline"]:
+            out["speedup_vs_single_socket_extrapolated"] = out["value"] / out["cpu_baseline"]["single_socket_extrapolated_iter_s"]
+    print(json.dumps(out))
 
 
-def bench_query_sharded(args, rank, world, dev, cdev, gpu_index, dist):
-    """One frame pair, queries split over the ranks (batch.align_query_sharded): per iteration
-    every rank runs K1/K2 on its slice, then ONE all-reduce of 19 sums + count (RCCL, 160 bytes)
-    and a replicated 3x3 solve.  The loop is host-driven (the collective sits between K2 and
-    the solve), so this mode pays one stream sync + one collective latency per iteration."""
-    import torch
+def frame_batch_one_gpu(args, torch, dev, gpu_index, single_value):
+    """BASELINE configs[3] on one GPU: all 64 pairs through icpk_align_batch_device."""
+    from icp_slam_prototype_amd import binding
 
+    keep, pargs = batch_pairs_on_device(torch, dev, range(args.batch_pairs))
+    ctx = binding.Context(gpu_index)
+    params = binding.default_params(max_iterations=args.iters, fixed_iterations=1)
+    for _ in range(3):  # warm-up: allocates the slots; the runtime's pools settle within the first calls
+        T, st, rc = ctx.align_batch_device(pargs, params)
+    assert rc == 0 and all(s.iterations == args.iters for s in st)
+    reps = 5
+    each = []
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        T, st, rc = ctx.align_batch_device(pargs, params)
+        torch.cuda.synchronize()
+        each.append(time.perf_counter() - t0)
+    dt = statistics.median(each)
+    ctx.close()
+    total_iters = sum(s.iterations for s in st)
+    return {"workload": f"{args.batch_pairs} distinct config-2 pairs (seeds {BATCH_SEED0}..{BATCH_SEED0 + args.batch_pairs - 1}), "
+                        f"{args.iters} fixed iterations each, resident in HBM, icpk_align_batch_device on ONE GPU "
+                        f"(lock-step groups of {os.environ.get('ICPK_BATCH_GROUP', '16')})",
+            "value": total_iters / dt, "unit": "iter/s", "ms_per_batch": dt * 1e3, "ms_per_pair": dt * 1e3 / args.batch_pairs,
+            "vs_single_pair": total_iters / dt / single_value, "reps": reps, "timing": "median of 5 calls, host wall clock, "
+            "device idle before and after each call", "ms_each": [round(t * 1e3, 3) for t in each]}
+
+
+def extra_workload(args, torch, dev, gpu_index, name, iters, steps):
+    """the 'also run' variants of SURVEY.md 8d, driver-visible: same timing method as the headline"""
+    from icp_slam_prototype_amd import binding
+
+    w = make_workload(name, 2 if name != "dense1m" else 5)
+    src_d, tgt_d = upload(torch, dev, w["source"]), upload(torch, dev, w["target"])
+    torch.cuda.synchronize()
+    nq, nt = src_d.shape[1], tgt_d.shape[1]
+    ctx = binding.Context(gpu_index)
+    set_clouds_device(ctx, src_d, tgt_d)
+    params = binding.default_params(max_iterations=iters, fixed_iterations=1)
+    elapsed, iters_done, nn_launches, nn_timed, nn_ms = timed_alignments(torch, ctx, params, steps, 2, torch.cuda.synchronize)
+    ctx.close()
+    avg_nn_s = nn_ms / max(nn_timed, 1) / 1e3
+    phys, yard = roofline_blocks(name, "grid", nq, nt, avg_nn_s, f"as the headline ({nn_timed} of {nn_launches} launches)",
+                                 "nn_grid_kernel<8|4,false|true>")
+    return {"workload": f"{name}: {nq} x {nt} points, {iters} fixed iterations per step, {steps} steps",
+            "value": iters_done / elapsed, "unit": "iter/s", "ms_per_step": elapsed / steps * 1e3,
+            "nn_mpoints_per_s": nn_launches * nq / elapsed / 1e6, "roofline": phys, "roofline_algorithmic": yard}
+
+
+# --------------------------------------------------------------------------------- N > 1 --
+def bench_frame_batch(args, torch, dist, rank, world, dev, cdev, gpu_index, rehearsal):
+    """BASELINE configs[3]: 64 pairs block-partitioned over the ranks."""
     from icp_slam_prototype_amd import batch, binding
 
+    n_pairs = args.batch_pairs
+    start, count = batch.partition(n_pairs, world, rank)
+    keep, pargs = batch_pairs_on_device(torch, dev, range(start, start + count))
+    ctx = binding.Context(gpu_index)
+    comm = None
+    comm_err = None
+    if args.comm in ("auto", "icpk") and not rehearsal:
+        def exchange(uid):  # rank 0's 128-byte id to everybody, over the launcher's process group
+            box = [uid]
+            dist.broadcast_object_list(box, src=0)
+            return box[0]
+
+        try:
+            comm = batch.RcclComm(ctx, rank, world, exchange)
+        except Exception as e:  # noqa: BLE001 -- fall back to torch.distributed, and say so in the line
+            if args.comm == "icpk":
+                raise
+            comm_err = repr(e)
+    ok = torch.tensor([1 if comm is not None else 0], device=cdev)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if int(ok.item()) == 0:  # not every rank got an RCCL communicator through the C ABI
+        if comm is not None:
+            comm.close()
+        comm = batch.TorchComm(dist, cdev)
+    params = binding.default_params(max_iterations=args.iters, fixed_iterations=1)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    def step():
+        T, st, rc = ctx.align_batch_device(pargs, params)
+        if isinstance(comm, batch.RcclComm):
+            Tg, Sg = comm.gather_results(T, st, n_pairs)
+        else:
+            Tg, Sg = comm.gather_results(T, batch.stats_rows(st), n_pairs)
+        return rc, Tg, Sg
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        rc, Tg, Sg = step()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    tt = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    elapsed = float(tt.item())
+    # every rank holds the same gathered result, every pair ran its 20 iterations
+    chk = torch.tensor(np.concatenate([Tg.reshape(-1), Sg.reshape(-1)]).astype(np.float64), device=cdev)
+    lo, hi = chk.clone(), chk.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    consistent = bool(torch.equal(lo, hi)) and rc == 0 and bool((Sg[:, 0] == args.iters).all()) and bool((Sg[:, 1] == 0).all())
+    # key-frame broadcast (north_star: RCCL broadcast of the target cloud over xGMI), untimed
+    # part of the run: rank 0's first target becomes every rank's target; median of 5
+    bcast_ms = None
+    if isinstance(comm, batch.RcclComm):
+        t_h = keep[0][1].cpu().numpy() if count else np.zeros((3, 1), np.float32)
+        if rank == 0:
+            ctx.set_target(t_h)
+        ts = []
+        for _ in range(5):
+            sync_all()
+            tb = time.perf_counter()
+            comm.broadcast_target(0)
+            ts.append((time.perf_counter() - tb) * 1e3)
+        bcast_ms = statistics.median(ts)
+        nt0 = ctx.target_size
+    if rank == 0:
+        total_iters = float(Sg[:, 0].sum()) * args.steps
+        out = {
+            "metric": METRIC, "value": total_iters / elapsed, "unit": "iter/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[3]: {n_pairs} distinct config-2 frame pairs (640x480, 30 % valid, seeds "
+                                   f"{BATCH_SEED0}..{BATCH_SEED0 + n_pairs - 1}, ~92k x 92k points each), {args.iters} fixed ICP "
+                                   f"iterations each per step, {n_pairs}/{world} pairs per GPU, clouds resident in HBM",
+                       "frame_pairs_per_step": n_pairs, "pairs_per_gpu": count,
+                       "parallelism": f"frame-batch x{world}: block partition, no per-iteration collective, one all-gather "
+                                      f"of the results per step"},
+            "collectives": comm.kind, "collectives_fallback_reason": comm_err,
+            "results_consistent_on_all_ranks": consistent,
+            "keyframe_broadcast_ms": bcast_ms,
+            "keyframe_broadcast_bytes": (3 * 4 * nt0) if bcast_ms is not None else None,
+            "note": "N = 1 of this bench reports the single-pair configs[1] rate as `value` and this same 64-pair batch on "
+                    "one GPU as `frame_batch.value`: scale the N > 1 lines against the latter",
+        }
+        print(json.dumps(out))
+    if isinstance(comm, batch.RcclComm):
+        comm.close()
+    ctx.close()
+
+
+def bench_query_sharded(args, torch, dist, rank, world, dev, cdev, gpu_index):
+    """One frame pair, queries split over the ranks (batch.align_query_sharded): per iteration
+    every rank runs K1/K2 on its slice, then ONE all-reduce of 19 sums + count (160 bytes) and a
+    replicated 3x3 solve.  The loop is host-driven (the collective sits between K2 and the
+    solve), so this mode pays one stream sync + one collective latency per iteration."""
+    from icp_slam_prototype_amd import batch, binding
+
+    comm = batch.TorchComm(dist, cdev)
     w = make_workload(args.workload, 2)
-    tgt = batch.broadcast_cloud(w["target"] if rank == 0 else None, 0, cdev, dist).cpu().numpy()
+    tgt = comm.broadcast_cloud(w["target"] if rank == 0 else None, 0).cpu().numpy()
     nq_total = w["source"].shape[1]
     s0, cnt = batch.partition(nq_total, world, rank)
     src = np.ascontiguousarray(w["source"][:, s0:s0 + cnt])
     ctx = binding.Context(gpu_index)
     ctx.set_target(tgt)
     ctx.set_source(src)
-    steps = batch.ContextSteps(ctx, {"exact": binding.NN_EXACT, "filtered": binding.NN_FILTERED,
-                                     "pruned": binding.NN_PRUNED, "grid": binding.NN_GRID}[args.nn_mode])
+    modes = {"exact": binding.NN_EXACT, "filtered": binding.NN_FILTERED, "pruned": binding.NN_PRUNED, "grid": binding.NN_GRID}
+    steps = batch.ContextSteps(ctx, modes[args.nn_mode])
     solve = {"reference": 0, "kabsch": 1}.get(args.solve)
     if solve is None:
         raise SystemExit("--shard queries supports --solve reference|kabsch")
 
     def one_step():
         ctx.reset_source()
-        return batch.align_query_sharded(steps, dist, cdev, max_iterations=args.iters, solve=solve,
-                                         fixed_iterations=True)
+        return batch.align_query_sharded(steps, comm, max_iterations=args.iters, solve=solve, fixed_iterations=True)
 
     for _ in range(args.warmup):
         one_step()
@@ -347,17 +591,59 @@ def bench_query_sharded(args, rank, world, dev, cdev, gpu_index, dist):
     elapsed = float(tt.item())
     if rank == 0:
         print(json.dumps({
-            "metric": "ICP iterations/sec + NN Mpoints/sec at 307k-pt Kinect cloud, 1/2/4/8 GPU",
-            "value": iters / elapsed, "unit": "iter/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "f32 filter + f64 exact pair arithmetic, f64 reductions", "data": "synthetic",
+            "metric": METRIC, "value": iters / elapsed, "unit": "iter/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
             "config": {"workload": f"{args.workload}: {nq_total} source x {tgt.shape[1]} target points, {args.iters} "
                                    f"fixed ICP iterations per step, solve={args.solve}, nn={args.nn_mode}",
                        "parallelism": f"query-sharded x{world}, 1 all-reduce(160 B)/iteration"},
             "nn_mpoints_per_s": iters * nq_total / elapsed / 1e6}))
     ctx.close()
-    dist.barrier()
-    dist.destroy_process_group()
+
+
+def main():
+    args = parse()
+    if args.cpu_baseline_child:
+        print(json.dumps(cpu_baseline_child(args.workload)))
+        return
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: N > 1 must be launched with one process per GPU "
+                         f"(python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} ... bench.py --gpus {args.gpus})")
+
+    import torch  # before the binding: libicpk.so must bind to the HIP runtime torch ships
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    # Rehearsal on a 1-GPU box (never used by the driver): ICPK_BENCH_REHEARSAL=1 maps every
+    # rank to cuda:0 and runs the collectives over gloo, because RCCL refuses two ranks on
+    # one device.  The real multi-GPU run uses RCCL (behind the C ABI; backend "nccl" for the
+    # launcher's own process group).
+    rehearsal = os.environ.get("ICPK_BENCH_REHEARSAL") == "1"
+    gpu_index = 0 if rehearsal else local_rank
+    torch.cuda.set_device(gpu_index)
+    dev = torch.device("cuda", gpu_index)
+    if world == 1:
+        return bench_single(args, torch, dev, gpu_index)
+
+    import torch.distributed as dist
+
+    cdev = torch.device("cpu") if rehearsal else dev  # device of the tensors handed to torch collectives
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if rehearsal:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    else:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    try:
+        if args.shard == "queries":
+            bench_query_sharded(args, torch, dist, rank, world, dev, cdev, gpu_index)
+        else:
+            bench_frame_batch(args, torch, dist, rank, world, dev, cdev, gpu_index, rehearsal)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

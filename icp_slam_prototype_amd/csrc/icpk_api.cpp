@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -219,28 +220,21 @@ int prepare_pruned_target(icpk_ctx* ctx, NnBoxes& bx) {
   return ICPK_OK;
 }
 
-// cell table + cell-sorted AoS copy of the target for the grid scan (once per target cloud)
-int ensure_scan_buffers(icpk_ctx* ctx, int n) {
+// counts / starts of the counting sorts by cell (targets: cell_start; queries: qstart)
+int ensure_scan_buffers(icpk_ctx* ctx) {
   if (!ctx->qcount) ICPK_HIP(ctx, hipMalloc((void**)&ctx->qcount, ((size_t)GRID_MAX_CELLS + 1) * sizeof(int)));
   if (!ctx->qstart) ICPK_HIP(ctx, hipMalloc((void**)&ctx->qstart, ((size_t)GRID_MAX_CELLS + 1) * sizeof(int)));
-  const size_t need = scan_temp_bytes(n);
-  if (need > ctx->scan_temp_bytes) {
-    if (ctx->scan_temp) ICPK_HIP(ctx, hipFree(ctx->scan_temp));
-    ctx->scan_temp = nullptr;
-    ctx->scan_temp_bytes = 0;
-    ICPK_HIP(ctx, hipMalloc(&ctx->scan_temp, need));
-    ctx->scan_temp_bytes = need;
-  }
+  if (!ctx->scan_bsum) ICPK_HIP(ctx, hipMalloc((void**)&ctx->scan_bsum, (size_t)GRID_SCAN_BLOCKS * sizeof(int)));
   return ICPK_OK;
 }
 
-// phase 1: bounds and cell size of the current target, read-back of the 36-byte GridInfo enqueued
-// (the host needs the grid's size to dimension the counting sorts)
-int grid_target_phase1(icpk_ctx* ctx) {
+// cell table + cell-sorted AoS copy of the target for the grid scan (once per target cloud).
+// Everything is enqueued: the grid's size stays on the device (GridInfo), the counting sort's
+// zero fill and scan read it there -- no host round trip, so the frame-batch mode can build the
+// next group's grids in the shadow of the running loop.
+int prepare_grid_target(icpk_ctx* ctx) {
   const int nt = ctx->tgt.n;
   if (!ctx->grid_info) ICPK_HIP(ctx, hipMalloc((void**)&ctx->grid_info, sizeof(GridInfo)));
-  if (!ctx->grid_host_pin)
-    ICPK_HIP(ctx, hipHostMalloc((void**)&ctx->grid_host_pin, sizeof(GridInfo), hipHostMallocDefault));
   if (!ctx->grid_bounds)
     ICPK_HIP(ctx, hipMalloc((void**)&ctx->grid_bounds, (size_t)GRID_BOUNDS_PARTS * 6 * sizeof(float)));
   if (!ctx->cell_start) ICPK_HIP(ctx, hipMalloc((void**)&ctx->cell_start, ((size_t)GRID_MAX_CELLS + 1) * sizeof(int)));
@@ -252,41 +246,22 @@ int grid_target_phase1(icpk_ctx* ctx) {
     ctx->t4_cap = round_up(nt, NN_TILE);
     ctx->have_grid = false;
   }
-  if (ctx->have_grid || ctx->grid_phase1) return ICPK_OK;
+  if (ctx->have_grid) return ICPK_OK;
   int rc = ensure_sort_buffers(ctx, nt);
+  if (rc) return rc;
+  rc = ensure_scan_buffers(ctx);
   if (rc) return rc;
   launch_grid_bounds(ctx->tgt.x(), ctx->tgt.y(), ctx->tgt.z(), nt, ctx->grid_bounds, ctx->stream);
   launch_grid_info(ctx->grid_bounds, nt, ctx->grid_ppc, ctx->grid_info, ctx->stream);
-  ICPK_HIP(ctx, hipMemcpyAsync(ctx->grid_host_pin, ctx->grid_info, sizeof(GridInfo), hipMemcpyDeviceToHost, ctx->stream));
-  ctx->grid_phase1 = true;
-  return ICPK_OK;
-}
-
-// cell table + cell-sorted AoS copy of the target for the grid scan (once per target cloud)
-int prepare_grid_target(icpk_ctx* ctx) {
-  const int nt = ctx->tgt.n;
-  int rc = grid_target_phase1(ctx);
-  if (rc) return rc;
-  if (ctx->have_grid) return ICPK_OK;
-  // set-up path: one stream sync per target cloud
-  ICPK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  ctx->grid_phase1 = false;
-  ctx->grid_host = *ctx->grid_host_pin;
-  const int ncells = ctx->grid_host.ncells;
-  if (ncells < 1 || ncells > GRID_MAX_CELLS) return fail(ctx, ICPK_E_HIP, "grid info not available");
-  rc = ensure_scan_buffers(ctx, ncells + 1);
-  if (rc) return rc;
   // counting sort of the targets by cell: slot within the cell by atomics (the order inside a
   // cell is irrelevant: candidates are merged lexicographically), cell starts by an exclusive
   // scan of the counts (entry ncells = Nt), scatter into the AoS copy
   int* tcell = reinterpret_cast<int*>(ctx->sort_keys + ctx->sort_cap);
   int* tslot = ctx->sort_vals;
-  ICPK_HIP(ctx, hipMemsetAsync(ctx->qcount, 0, ((size_t)ncells + 1) * sizeof(int), ctx->stream));
+  launch_grid_zero_counts(ctx->qcount, ctx->grid_info, ctx->stream);
   launch_grid_qslot(ctx->tgt.x(), ctx->tgt.y(), ctx->tgt.z(), nt, ctx->grid_info, ctx->qcount, tcell, tslot,
                     ctx->stream);
-  if (launch_exclusive_scan(ctx->scan_temp, ctx->scan_temp_bytes, ctx->qcount, ctx->cell_start, ncells + 1,
-                            ctx->stream) != 0)
-    return fail(ctx, ICPK_E_HIP, "rocprim::exclusive_scan failed");
+  launch_grid_scan(ctx->qcount, ctx->cell_start, ctx->scan_bsum, ctx->grid_info, ctx->stream);
   launch_grid_tscatter(ctx->tgt.x(), ctx->tgt.y(), ctx->tgt.z(), tcell, tslot, ctx->cell_start, nt, ctx->t4,
                        ctx->stream);
   ICPK_HIP(ctx, hipGetLastError());
@@ -297,19 +272,16 @@ int prepare_grid_target(icpk_ctx* ctx) {
 // query order for the grid scan: counting sort of the source by cell of the target's grid
 int enqueue_cell_order(icpk_ctx* ctx) {
   const int nq = ctx->src.n;
-  const int ncells = ctx->grid_host.ncells;
-  if (ncells < 1 || ncells > GRID_MAX_CELLS) return fail(ctx, ICPK_E_HIP, "grid info not available");
   int rc = ensure_sort_buffers(ctx, nq);
   if (rc) return rc;
-  rc = ensure_scan_buffers(ctx, ncells);
+  rc = ensure_scan_buffers(ctx);
   if (rc) return rc;
   int* qcell = reinterpret_cast<int*>(ctx->sort_keys + ctx->sort_cap);
   int* qslot = ctx->sort_vals;
-  ICPK_HIP(ctx, hipMemsetAsync(ctx->qcount, 0, (size_t)ncells * sizeof(int), ctx->stream));
+  launch_grid_zero_counts(ctx->qcount, ctx->grid_info, ctx->stream);
   launch_grid_qslot(ctx->src.x(), ctx->src.y(), ctx->src.z(), nq, ctx->grid_info, ctx->qcount, qcell, qslot,
                     ctx->stream);
-  if (launch_exclusive_scan(ctx->scan_temp, ctx->scan_temp_bytes, ctx->qcount, ctx->qstart, ncells, ctx->stream) != 0)
-    return fail(ctx, ICPK_E_HIP, "rocprim::exclusive_scan failed");
+  launch_grid_scan(ctx->qcount, ctx->qstart, ctx->scan_bsum, ctx->grid_info, ctx->stream);
   launch_grid_qscatter(qcell, qslot, ctx->qstart, nq, ctx->qperm, ctx->stream);
   ICPK_HIP(ctx, hipGetLastError());
   return ICPK_OK;
@@ -602,7 +574,6 @@ int icpk_host_target_replaced(icpk_ctx* ctx) {
   ctx->have_dec = false;
   ctx->have_boxes = false;
   ctx->have_grid = false;
-  ctx->grid_phase1 = false;
   ctx->have_seed = false;
   ctx->have_normals = false;
   return ICPK_OK;
@@ -688,6 +659,10 @@ int icpk_create(icpk_ctx** out, int device_id) {
     const int v = std::atoi(e);
     if (v >= 1 && v <= BATCH_MAX) ctx->batch_group = v;
   }
+  if (const char* e = std::getenv("ICPK_BATCH_THREADS")) {
+    const int v = std::atoi(e);
+    if (v >= 1 && v <= 16) ctx->batch_threads = v;
+  }
   *out = ctx;
   return ICPK_OK;
 }
@@ -701,9 +676,8 @@ void icpk_destroy(icpk_ctx* ctx) {
   ctx->slots.clear();
   for (hipEvent_t e : {ctx->ready_ev, ctx->group_ev[0], ctx->group_ev[1]})
     if (e) (void)hipEventDestroy(e);
-  if (ctx->grid_host_pin) (void)hipHostFree(ctx->grid_host_pin);
   for (hipEvent_t e : ctx->events) (void)hipEventDestroy(e);
-  void* dev[] = {ctx->qcount, ctx->qstart, ctx->scan_temp, ctx->qm4, ctx->sp_in, ctx->sp_out, ctx->grid_info, ctx->grid_bounds, ctx->cell_start, ctx->t4, ctx->best_m, ctx->seed_m, ctx->st_dev, ctx->sorted.base, ctx->tkeys, ctx->tperm, ctx->qperm, ctx->bounds, ctx->sort_keys, ctx->sort_vals, ctx->sort_temp,
+  void* dev[] = {ctx->qcount, ctx->qstart, ctx->scan_bsum, ctx->qm4, ctx->sp_in, ctx->sp_out, ctx->grid_info, ctx->grid_bounds, ctx->cell_start, ctx->t4, ctx->best_m, ctx->seed_m, ctx->st_dev, ctx->sorted.base, ctx->tkeys, ctx->tperm, ctx->qperm, ctx->bounds, ctx->sort_keys, ctx->sort_vals, ctx->sort_temp,
                  ctx->nrm.base, ctx->boxes, ctx->dec.base, ctx->tgt.base, ctx->src0.base, ctx->src.base, ctx->best,      ctx->seed,     ctx->idx,
                  ctx->dist,     ctx->partial,   ctx->pcount,   ctx->red_out,   ctx->depth_dev, ctx->bp_counts};
   for (void* p : dev)
@@ -738,7 +712,6 @@ static int set_target_impl(icpk_ctx* ctx, const float* x, const float* y, const 
   ctx->have_dec = false;
   ctx->have_boxes = false;
   ctx->have_grid = false;
-  ctx->grid_phase1 = false;
   ctx->have_seed = false;
   ctx->have_normals = false;
   return ICPK_OK;
@@ -1082,7 +1055,6 @@ int icpk_transform_target(icpk_ctx* ctx, const float R[9], const float t[3]) {
   ctx->have_dec = false;
   ctx->have_boxes = false;
   ctx->have_grid = false;
-  ctx->grid_phase1 = false;
   ctx->have_seed = false;
   ICPK_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return ICPK_OK;
@@ -1369,9 +1341,7 @@ int slot_setup_phase1(icpk_ctx* sl, const icpk_pair& pr, hipMemcpyKind kind) {
   if (sl->src.n <= 0) return ICPK_OK;  // an empty source takes the single-pair path
   sl->have_seed = false;
   sl->have_qperm = false;
-  rc = ensure_assoc(sl, sl->src.n);
-  if (rc) return rc;
-  return grid_target_phase1(sl);
+  return ensure_assoc(sl, sl->src.n);
 }
 
 // grid of the target (waits for its 36-byte info), query order, scan-order queries and seeds,
@@ -1537,43 +1507,75 @@ int align_batch_impl(icpk_ctx* ctx, int32_t n_pairs, const icpk_pair* pairs, con
     return ICPK_OK;
   };
 
+  // ICPK_BATCH_TRACE=1 (diagnostic): host time per group in set-up phase 1 / phase 2 / loop
+  // enqueue / waiting for the previous group, on stderr
+  const bool trace = std::getenv("ICPK_BATCH_TRACE") != nullptr;
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+    return std::chrono::duration<double, std::micro>(b - a).count();
+  };
   GroupRun prev;
   bool have_prev = false;
   for (int gi = 0; gi < ngroups; ++gi) {
-    GroupRun g;
+    const auto t0 = now();
+        GroupRun g;
     g.first = gi * G;
     g.count = n_pairs - g.first < G ? n_pairs - g.first : G;
     g.set = ngroups > 1 ? (gi & 1) : 0;
     g.rc.assign(g.count, ICPK_OK);
-    for (int k = 0; k < g.count; ++k)
-      g.rc[k] = slot_setup_phase1(ctx->slots[(size_t)g.set * G + k], pairs[g.first + k], kind);
+    // set-up of the group's pairs: independent per slot (own buffers, own stream), so a few host
+    // threads share the ~35 runtime calls per pair -- with 8 pairs per GPU (config 4 at 8 GPUs)
+    // there is no previous group whose loop could hide this host time
+    std::vector<GridSweepArgs> fargs(g.count);
+    auto setup_one = [&](int k) {
+      icpk_ctx* sl = ctx->slots[(size_t)g.set * G + k];
+      const int b = g.first + k;
+      int r = slot_setup_phase1(sl, pairs[b], kind);
+      if (r != ICPK_OK) {
+        g.rc[k] = r;
+        return;
+      }
+      if (sl->src.n <= 0) {  // no queries: the single-pair path handles it (icp.cpp:163-182 fallback)
+        r = icpk_align(sl, p, T_out + 16 * (size_t)b, stats ? stats + b : nullptr);
+        g.rc[k] = r < 0 ? r : 100 + r;
+        return;
+      }
+      r = slot_setup_phase2(sl, p, fargs[k]);
+      if (r != ICPK_OK) device_loop_disarm(sl);
+      g.rc[k] = r;
+    };
+    const int nthreads = g.count < ctx->batch_threads ? g.count : ctx->batch_threads;
+    if (nthreads <= 1) {
+      for (int k = 0; k < g.count; ++k) setup_one(k);
+    } else {
+      std::vector<std::thread> pool;
+      for (int t = 1; t < nthreads; ++t)
+        pool.emplace_back([&, t] {
+          for (int k = t; k < g.count; k += nthreads) setup_one(k);
+        });
+      for (int k = 0; k < g.count; k += nthreads) setup_one(k);
+      for (std::thread& th : pool) th.join();
+    }
+    const auto t1 = now();
     std::vector<icpk_ctx*> act;
     std::vector<GridSweepArgs> first;
     for (int k = 0; k < g.count; ++k) {
       if (g.rc[k] != ICPK_OK) continue;
-      icpk_ctx* sl = ctx->slots[(size_t)g.set * G + k];
-      const int b = g.first + k;
-      if (sl->src.n <= 0) {  // no queries: the single-pair path handles it (icp.cpp:163-182 fallback)
-        const int r = icpk_align(sl, p, T_out + 16 * (size_t)b, stats ? stats + b : nullptr);
-        g.rc[k] = r < 0 ? r : 100 + r;
-        continue;
-      }
-      GridSweepArgs fa{};
-      g.rc[k] = slot_setup_phase2(sl, p, fa);
-      if (g.rc[k] != ICPK_OK) {
-        device_loop_disarm(sl);
-        continue;
-      }
-      act.push_back(sl);
-      first.push_back(fa);
+      act.push_back(ctx->slots[(size_t)g.set * G + k]);
+      first.push_back(fargs[k]);
     }
+    const auto t2 = now();
     rc = enqueue_group_loop(ctx, p, act, first, g.set);
     if (rc) {  // enqueue failed: nothing of this group can be trusted
       for (icpk_ctx* sl : act) device_loop_disarm(sl);
       (void)hipStreamSynchronize(ctx->stream);
       return rc;
     }
+    const auto t3 = now();
     if (have_prev) finish_group(prev);
+    if (trace)
+      std::fprintf(stderr, "icpk batch group %d: set-up %.0f us (%d host threads), loop enqueue %.0f us, wait+finish prev %.0f us\n",
+                   gi, us(t0, t1), nthreads, us(t2, t3), us(t3, now()));
     prev = g;
     have_prev = true;
   }
@@ -1649,7 +1651,7 @@ static int backproject_impl(icpk_ctx* ctx, const uint16_t* depth, int32_t rows, 
   ctx->have_seed = false;
   ctx->have_qperm = false;
   if (which == 1) {
-    ctx->have_dec = ctx->have_boxes = ctx->have_grid = ctx->grid_phase1 = false;
+    ctx->have_dec = ctx->have_boxes = ctx->have_grid = false;
     ctx->have_normals = normals_mode >= 0;
     if (ctx->have_normals) ctx->nrm.n = n;
   }

@@ -93,23 +93,20 @@ struct icpk_ctx {
   float4* sp_in = nullptr;   // seeds as points, scan order: read by the next grid sweep
   float4* sp_out = nullptr;  // ... written by it
   int qm4_cap = 0;
-  GridInfo grid_host{};      // host copy of *grid_info (read back once per target)
-  GridInfo* grid_host_pin = nullptr;  // pinned landing buffer of that read-back (truly asynchronous copy)
-  bool grid_phase1 = false;  // bounds / info of the current target are enqueued, read-back in flight
   // frame-batch mode: child contexts (one per pair in flight; own stream for set-up work) --
   // owned by the parent, never handed out
   std::vector<icpk_ctx*> slots;
   hipEvent_t ready_ev = nullptr;       // slot: set-up of the current pair is enqueued up to here
   hipEvent_t group_ev[2] = {nullptr, nullptr};  // parent: the lock-step loop of a slot set has finished
-  int batch_group = 8;                 // pairs advancing in lock step (ICPK_BATCH_GROUP, <= BATCH_MAX)
+  int batch_group = 16;                // pairs advancing in lock step (ICPK_BATCH_GROUP, <= BATCH_MAX)
+  int batch_threads = 4;               // host threads sharing a group's set-up calls (ICPK_BATCH_THREADS)
   std::vector<nn_key_t*> best_of_sweep;  // device loop: which buffer each enqueued sweep wrote
   // RCCL communicator of the frame-batch / query-sharded modes (icpk_comm.cpp); null until
   // icpk_comm_init_rccl
   struct icpk_comm_state* comm = nullptr;
   int* qcount = nullptr;     // query counting sort by cell: counts and starts, GRID_MAX_CELLS + 1 each
   int* qstart = nullptr;
-  void* scan_temp = nullptr;
-  size_t scan_temp_bytes = 0;
+  int* scan_bsum = nullptr;  // block sums of the cell-count scans (GRID_SCAN_BLOCKS ints)
   int loop_nact = icpk::NSUM;      // device loop: sums the running alignment's step consumes (NSUM_REF or NSUM)
   int profile_phase = 0;     // alignments profiled so far (offsets the sampled launches, see profile_stride)
   int qperm_kind = 0;        // what qperm holds: 1 Morton order (pruned scan), 2 cell order (grid scan)

@@ -100,7 +100,7 @@ void launch_decimate(const float* x, const float* y, const float* z, int n, int 
                      int n_out_pad, hipStream_t s);
 // kernels_grid.hip: uniform grid over the target (ICPK_NN_GRID)
 constexpr int GRID_MAX_CELLS = 1 << 22;
-constexpr int GRID_BOUNDS_PARTS = 64;  // partial boxes of the bounds pass (6 floats each)
+constexpr int GRID_BOUNDS_PARTS = 256;  // partial boxes of the bounds pass (6 floats each)
 struct GridInfo {
   float lo[3];  // finite lower corner of the target
   float inv_h;  // 1 / cell edge
@@ -115,8 +115,9 @@ void launch_grid_tscatter(const float* x, const float* y, const float* z, const 
 void launch_grid_qslot(const float* x, const float* y, const float* z, int n, const GridInfo* g, int* count, int* qcell,
                        int* qslot, hipStream_t s);
 void launch_grid_qscatter(const int* qcell, const int* qslot, const int* qstart, int n, int* qperm, hipStream_t s);
-size_t scan_temp_bytes(int n);
-int launch_exclusive_scan(void* temp, size_t temp_bytes, const int* in, int* out, int n, hipStream_t s);
+constexpr int GRID_SCAN_BLOCKS = (GRID_MAX_CELLS + 1 + 2047) / 2048 + 1;  // scratch ints of launch_grid_scan
+void launch_grid_zero_counts(int* count, const GridInfo* g, hipStream_t s);
+void launch_grid_scan(const int* in, int* out, int* bsum, const GridInfo* g, hipStream_t s);
 // one pair's arguments of a grid sweep (K1d); see nn_grid_body
 struct GridSweepArgs {
   float *qx, *qy, *qz;  // the caller's source planes (kept in step when K3 is fused)

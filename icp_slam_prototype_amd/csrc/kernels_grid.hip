@@ -66,12 +66,21 @@ __global__ __launch_bounds__(1024) void grid_bounds_kernel(const float* __restri
 // GRID_MAX_CELLS cells.  Only efficiency depends on the choice.
 __global__ void grid_info_kernel(const float* __restrict__ fbp, int nparts, int n, float ppc,
                                  GridInfo* __restrict__ g) {
+  // one wave: lane l merges the partial boxes l, l + 64, ...; xor butterfly; lane 0 goes on
   float fb[6];
+#pragma unroll
   for (int c = 0; c < 6; ++c) {
-    float v = fbp[c];
-    for (int b = 1; b < nparts; ++b) v = c < 3 ? __builtin_fminf(v, fbp[b * 6 + c]) : __builtin_fmaxf(v, fbp[b * 6 + c]);
+    float v = c < 3 ? __builtin_inff() : -__builtin_inff();
+    for (int b = threadIdx.x; b < nparts; b += 64)
+      v = c < 3 ? __builtin_fminf(v, fbp[b * 6 + c]) : __builtin_fmaxf(v, fbp[b * 6 + c]);
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+      const float o = __shfl_xor(v, m, 64);
+      v = c < 3 ? __builtin_fminf(v, o) : __builtin_fmaxf(v, o);
+    }
     fb[c] = v;
   }
+  if (threadIdx.x != 0) return;
   float lo[3], ext[3];
   float emax = 0.f;
   for (int c = 0; c < 3; ++c) {
@@ -139,6 +148,127 @@ __global__ void grid_qscatter_kernel(const int* __restrict__ qcell, const int* _
   if (i < n) qperm[qstart[qcell[i]] + qslot[i]] = i;
 }
 
+// ---- device-sized zero fill and exclusive scan of the cell counts -------------------------
+// The number of cells lives in GridInfo ON THE DEVICE; these kernels read it there, so the whole
+// grid build is enqueued without a host round trip (the frame-batch mode builds the grids of the
+// next group while the current group's loop keeps the GPU busy: a host wait there costs
+// milliseconds).  Launch geometry covers GRID_MAX_CELLS + 1; workgroups beyond the actual size
+// leave at once.  Scan: 2048 counts per workgroup (256 lanes x 8), block sums, one workgroup
+// scans the <= 2049 block sums, then every block scans its own counts from its offset.
+constexpr int GSCAN_ITEMS = 8;
+constexpr int GSCAN_TILE = 256 * GSCAN_ITEMS;
+constexpr int GSCAN_MAX_BLOCKS = (GRID_MAX_CELLS + 1 + GSCAN_TILE - 1) / GSCAN_TILE;  // 2049
+
+__global__ __launch_bounds__(256) void grid_zero_counts_kernel(int* __restrict__ count,
+                                                               const GridInfo* __restrict__ gi) {
+  const int n = gi->ncells + 1;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) count[i] = 0;
+}
+
+__device__ __forceinline__ int block_sum_256(int v, int* sh) {  // sum over the 256 lanes, in every lane
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  const int t = sh[0] + sh[1] + sh[2] + sh[3];
+  __syncthreads();
+  return t;
+}
+
+__global__ __launch_bounds__(256) void grid_scan_sums_kernel(const int* __restrict__ in,
+                                                             const GridInfo* __restrict__ gi,
+                                                             int* __restrict__ bsum) {
+  __shared__ int sh[4];
+  const int n = gi->ncells + 1;
+  const int base = blockIdx.x * GSCAN_TILE;
+  if (base >= n) return;
+  int v = 0;
+#pragma unroll
+  for (int k = 0; k < GSCAN_ITEMS; ++k) {
+    const int i = base + k * 256 + threadIdx.x;
+    v += i < n ? in[i] : 0;
+  }
+  const int t = block_sum_256(v, sh);
+  if (threadIdx.x == 0) bsum[blockIdx.x] = t;
+}
+
+__global__ __launch_bounds__(1024) void grid_scan_offsets_kernel(int* __restrict__ bsum,
+                                                                 const GridInfo* __restrict__ gi) {
+  // exclusive scan of the nb <= 2049 block sums in place: 3 per lane, wave scan, 16 wave totals
+  __shared__ int wtot[16];
+  const int n = gi->ncells + 1;
+  const int nb = (n + GSCAN_TILE - 1) / GSCAN_TILE;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  int a[3], s = 0;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int i = 3 * t + k;
+    a[k] = i < nb ? bsum[i] : 0;
+    s += a[k];
+  }
+  int inc = s;  // inclusive scan over the wave
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int o = __shfl_up(inc, d, 64);
+    if (lane >= d) inc += o;
+  }
+  if (lane == 63) wtot[wave] = inc;
+  __syncthreads();
+  int woff = 0;
+  for (int w = 0; w < wave; ++w) woff += wtot[w];
+  int run = woff + inc - s;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int i = 3 * t + k;
+    if (i < nb) bsum[i] = run;
+    run += a[k];
+  }
+}
+
+__global__ __launch_bounds__(256) void grid_scan_apply_kernel(const int* __restrict__ in,
+                                                              const GridInfo* __restrict__ gi,
+                                                              const int* __restrict__ boff, int* __restrict__ out) {
+  __shared__ int wtot[4];
+  const int n = gi->ncells + 1;
+  const int base = blockIdx.x * GSCAN_TILE;
+  if (base >= n) return;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  // lane t owns the 8 consecutive counts base + 8 t .. base + 8 t + 7
+  int a[GSCAN_ITEMS], s = 0;
+#pragma unroll
+  for (int k = 0; k < GSCAN_ITEMS; ++k) {
+    const int i = base + GSCAN_ITEMS * t + k;
+    a[k] = i < n ? in[i] : 0;
+    s += a[k];
+  }
+  int inc = s;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int o = __shfl_up(inc, d, 64);
+    if (lane >= d) inc += o;
+  }
+  if (lane == 63) wtot[wave] = inc;
+  __syncthreads();
+  int run = boff[blockIdx.x] + inc - s;
+  for (int w = 0; w < wave; ++w) run += wtot[w];
+#pragma unroll
+  for (int k = 0; k < GSCAN_ITEMS; ++k) {
+    const int i = base + GSCAN_ITEMS * t + k;
+    if (i < n) out[i] = run;
+    run += a[k];
+  }
+}
+
+void launch_grid_zero_counts(int* count, const GridInfo* g, hipStream_t s) {
+  hipLaunchKernelGGL(grid_zero_counts_kernel, dim3(512), dim3(256), 0, s, count, g);
+}
+// out[i] = sum of in[0 .. i) for i in [0, ncells]; bsum: GRID_SCAN_BLOCKS ints of scratch
+void launch_grid_scan(const int* in, int* out, int* bsum, const GridInfo* g, hipStream_t s) {
+  hipLaunchKernelGGL(grid_scan_sums_kernel, dim3(GSCAN_MAX_BLOCKS), dim3(256), 0, s, in, g, bsum);
+  hipLaunchKernelGGL(grid_scan_offsets_kernel, dim3(1), dim3(1024), 0, s, bsum, g);
+  hipLaunchKernelGGL(grid_scan_apply_kernel, dim3(GSCAN_MAX_BLOCKS), dim3(256), 0, s, in, g, bsum, out);
+}
+
 // targets into the AoS copy (x, y, z, original index), one 16-byte load per candidate
 __global__ void grid_tscatter_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                      const float* __restrict__ z, const int* __restrict__ tcell,
@@ -165,15 +295,15 @@ void launch_grid_qscatter(const int* qcell, const int* qslot, const int* qstart,
   hipLaunchKernelGGL(grid_qscatter_kernel, dim3((n + 255) / 256), dim3(256), 0, s, qcell, qslot, qstart, n, qperm);
 }
 
-int grid_bounds_parts(int n) {
-  int nb = (n + 16383) / 16384;
+int grid_bounds_parts(int n) {  // one 1024-thread block per 2048 points, at most GRID_BOUNDS_PARTS
+  int nb = (n + 2047) / 2048;
   return nb < 1 ? 1 : (nb > GRID_BOUNDS_PARTS ? GRID_BOUNDS_PARTS : nb);
 }
 void launch_grid_bounds(const float* x, const float* y, const float* z, int n, float* fb, hipStream_t s) {
   hipLaunchKernelGGL(grid_bounds_kernel, dim3(grid_bounds_parts(n)), dim3(1024), 0, s, x, y, z, n, fb);
 }
 void launch_grid_info(const float* fb, int n, float ppc, GridInfo* g, hipStream_t s) {
-  hipLaunchKernelGGL(grid_info_kernel, dim3(1), dim3(1), 0, s, fb, grid_bounds_parts(n), n, ppc, g);
+  hipLaunchKernelGGL(grid_info_kernel, dim3(1), dim3(64), 0, s, fb, grid_bounds_parts(n), n, ppc, g);
 }
 
 // ---- the sweep --------------------------------------------------------------------------

@@ -12,7 +12,6 @@
 #include <cstring>
 
 #include <rocprim/device/device_radix_sort.hpp>
-#include <rocprim/device/device_scan.hpp>
 
 #include "icpk_internal.h"
 
@@ -94,16 +93,7 @@ int launch_sort_pairs(void* temp, size_t temp_bytes, const unsigned* keys_in, un
   return (int)rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0, 32, s);
 }
 
-size_t scan_temp_bytes(int n) {
-  size_t bytes = 0;
-  (void)rocprim::exclusive_scan(nullptr, bytes, (const int*)nullptr, (int*)nullptr, 0, (size_t)n, rocprim::plus<int>(),
-                                (hipStream_t) nullptr);
-  return bytes;
-}
 
-int launch_exclusive_scan(void* temp, size_t temp_bytes, const int* in, int* out, int n, hipStream_t s) {
-  return (int)rocprim::exclusive_scan(temp, temp_bytes, in, out, 0, (size_t)n, rocprim::plus<int>(), s);
-}
 
 // out[k] = in[perm[k]] for k < n, pad beyond (planes are NN_TILE-padded)
 __global__ void gather_planes_kernel(const float* __restrict__ x, const float* __restrict__ y,

@@ -213,7 +213,7 @@ int icpk_get_trace(icpk_ctx *ctx, int32_t *n_iter, float *R_out, float *t_out, i
 /* frame-batch mode (the frame-pair formulation of icp.cpp:541-563): n_pairs
  * independent pairs on this context's device; T_out n_pairs x 16, stats n_pairs (or NULL).
  * With the default kernels (ICPK_NN_GRID, device-side loop, reference or Kabsch flavour) up to
- * ICPK_BATCH_GROUP (default 8, at most 16) pairs advance in lock step -- one launch per stage
+ * ICPK_BATCH_GROUP (default and at most 16) pairs advance in lock step -- one launch per stage
  * for the whole group -- while the next group is being uploaded and indexed; every pair's
  * result equals icpk_align on that pair bit for bit.  Other settings run the pairs one after
  * the other.  The context's own clouds are not touched by the lock-step path.  Per-launch

@@ -32,16 +32,21 @@ for _ in range(10):
 dt = (time.perf_counter() - t0) / 10
 print(f"single pair resident: {dt*1e3:.3f} ms/alignment  {iters/dt:.0f} iter/s", flush=True)
 ctx.close()
-for g in [int(v) for v in os.environ.get("GROUPS", "1,2,4,8,16").split(",")]:
+for g in [int(v) for v in os.environ.get("BGROUPS", "1,2,4,8,16").split(",")]:
     os.environ["ICPK_BATCH_GROUP"] = str(g)
     c = binding.Context(0)
     for _ in range(2):
         c.align_batch_device(args, par)
-    reps = 3
+    reps = int(os.environ.get("REPS", 3))
+    each = []
     t0 = time.perf_counter()
     for _ in range(reps):
+        t1 = time.perf_counter()
         T, st, rc = c.align_batch_device(args, par)
+        each.append(round((time.perf_counter() - t1) * 1e3, 2))
     dt = (time.perf_counter() - t0) / reps
+    if os.environ.get("EACH"):
+        print("   per rep ms:", each, flush=True)
     assert rc == 0 and all(x.iterations == iters for x in st)
     print(f"group {g:2d}: {n_pairs} pairs in {dt*1e3:.2f} ms  = {dt/n_pairs*1e3:.3f} ms/pair  {n_pairs*iters/dt:.0f} iter/s", flush=True)
     c.close()
