@@ -18,6 +18,8 @@ E_ARG, E_EMPTY_TARGET, E_HIP, E_NOT_SET, E_NO_DEVICE, E_RCCL = -1, -2, -3, -4, -
 COMM_ID_BYTES = 128
 SOLVE_REFERENCE, SOLVE_KABSCH, SOLVE_POINT_TO_PLANE = 0, 1, 2
 W_DEGENERATE = 2
+W_EMPTY_MAP = 3
+MAX_NN_KEYPOINT_DISTANCE = 0.1  # icp.hpp:10
 NORMALS_CROSS, NORMALS_REFERENCE = 0, 1
 NP2L = 28
 NN_EXACT, NN_FILTERED, NN_PRUNED, NN_GRID = 0, 1, 2, 3
@@ -33,6 +35,7 @@ SYMBOLS = [
     "icpk_align_batch", "icpk_align_batch_device", "icpk_backproject", "icpk_backproject_with_normals", "icpk_set_target_normals",
     "icpk_get_target_normals", "icpk_reduce_p2l", "icpk_solve_point_to_plane", "icpk_pair_distance", "icpk_pair_distance3", "icpk_distance3", "icpk_make_rotation_matrix",
     "icpk_matrix_to_quaternion", "icpk_quaternion_to_euler", "icpk_solve_reference", "icpk_solve_kabsch",
+    "icpk_associate_keypoints", "icpk_filter_depth_image", "icpk_backproject_filtered",
     "icpk_comm_unique_id", "icpk_comm_init_rccl", "icpk_comm_destroy", "icpk_comm_rank", "icpk_comm_world",
     "icpk_comm_partition", "icpk_comm_broadcast_target", "icpk_comm_gather_results", "icpk_comm_allreduce_sums",
     "icpk_comm_barrier",
@@ -155,6 +158,12 @@ def load():
     dp = C.POINTER(C.c_double)
     lib.icpk_solve_kabsch.argtypes = [C.c_int64, dp, dp, dp, dp, dp]
     lib.icpk_solve_kabsch.restype = None
+    ip = C.POINTER(C.c_int32)
+    lib.icpk_associate_keypoints.argtypes = [C.c_void_p, C.c_int32, C.c_float, ip, ip, fp, ip, ip, C.c_int32, ip]
+    u16 = C.POINTER(C.c_uint16)
+    lib.icpk_filter_depth_image.argtypes = [C.c_void_p, u16, u16, C.c_int32, C.c_int32] + [C.c_int32] * 5
+    lib.icpk_backproject_filtered.argtypes = [C.c_void_p, u16, C.c_int32, C.c_int32, C.c_float, C.c_float, fp,
+                                              C.c_int32, C.c_int32] + [C.c_int32] * 5
     lib.icpk_comm_unique_id.argtypes = [C.c_void_p]
     lib.icpk_comm_init_rccl.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
     lib.icpk_comm_destroy.argtypes = [C.c_void_p]
@@ -403,6 +412,46 @@ class Context:
         n = self._chk(self._lib.icpk_backproject(self._h, depth.ctypes.data_as(C.POINTER(C.c_uint16)), rows, cols,
                                                  fx, cx, None if off is None else _fp(off), which))
         return n
+
+    def filter_depth_image(self, depth, max_d=25000, min_d=1000, morph=True, anchor=(-1, -1)):
+        """SLAM.cpp:553-574 on the device; anchor = (x, y) of dilate/erode, -1 = element centre."""
+        depth = np.ascontiguousarray(depth, np.uint16)
+        out = np.empty_like(depth)
+        rows, cols = depth.shape
+        u16 = C.POINTER(C.c_uint16)
+        self._chk(self._lib.icpk_filter_depth_image(self._h, depth.ctypes.data_as(u16), out.ctypes.data_as(u16), rows, cols,
+                                                    int(max_d), int(min_d), int(bool(morph)), int(anchor[0]), int(anchor[1])))
+        return out
+
+    def backproject_filtered(self, depth, which=0, normals_mode=-1, fx=468.60, cx=318.27, offset=None, max_d=25000,
+                             min_d=1000, morph=True, anchor=(-1, -1)):
+        depth = np.ascontiguousarray(depth, np.uint16)
+        rows, cols = depth.shape
+        off = None if offset is None else _f(offset)
+        return self._chk(self._lib.icpk_backproject_filtered(
+            self._h, depth.ctypes.data_as(C.POINTER(C.c_uint16)), rows, cols, fx, cx, None if off is None else _fp(off),
+            which, normals_mode, int(max_d), int(min_d), int(bool(morph)), int(anchor[0]), int(anchor[1])))
+
+    def associate_keypoints(self, max_dist=MAX_NN_KEYPOINT_DISTANCE, nn_mode=NN_GRID, rejected=None, capacity=None):
+        """icp.cpp:488-515 on the context's clouds.  rejected: the caller's running list of rejected
+        query indices (None = empty).  Returns (status, assoc_q, assoc_t, assoc_d, rejected) --
+        with status W_EMPTY_MAP the other entries are None / the unchanged list."""
+        n = self.source_size
+        prev = np.asarray([] if rejected is None else rejected, np.int32)
+        cap = prev.size + max(n, 1) if capacity is None else int(capacity)
+        aq = np.full(max(n, 1), -1, np.int32)
+        at = np.full(max(n, 1), -1, np.int32)
+        ad = np.full(max(n, 1), np.nan, np.float32)
+        rj = np.full(max(cap, 1), -1, np.int32)
+        rj[:prev.size] = prev
+        na, nr = C.c_int32(-1), C.c_int32(prev.size)
+        ip = C.POINTER(C.c_int32)
+        rc = self._chk(self._lib.icpk_associate_keypoints(self._h, nn_mode, max_dist, aq.ctypes.data_as(ip), at.ctypes.data_as(ip),
+                                                          _fp(ad), C.byref(na), rj.ctypes.data_as(ip), cap, C.byref(nr)))
+        if rc == W_EMPTY_MAP:
+            assert na.value == -1 and nr.value == prev.size  # untouched
+            return rc, None, None, None, prev
+        return rc, aq[:na.value].copy(), at[:na.value].copy(), ad[:na.value].copy(), rj[:nr.value].copy()
 
     # -- point-to-plane extension ------------------------------------------------
     def backproject_with_normals(self, depth, normals_mode=NORMALS_CROSS, fx=468.60, cx=318.27, offset=None):

@@ -11,7 +11,7 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libicpk.so")
 
 SOURCES = ["icpk_api.cpp", "icpk_comm.cpp", "kernels_nn.hip", "kernels_reduce.hip", "kernels_transform.hip",
-           "kernels_backproject.hip", "kernels_sort.hip", "kernels_nn_pruned.hip", "kernels_loop.hip", "kernels_grid.hip"]
+           "kernels_backproject.hip", "kernels_sort.hip", "kernels_nn_pruned.hip", "kernels_loop.hip", "kernels_grid.hip", "kernels_frontend.hip"]
 
 # -ffp-contract=off: the exact kernels spell out every fma they want; nothing may
 # be fused behind their back (host solve included).  No -ffast-math anywhere.

@@ -679,7 +679,7 @@ void icpk_destroy(icpk_ctx* ctx) {
   for (hipEvent_t e : ctx->events) (void)hipEventDestroy(e);
   void* dev[] = {ctx->qcount, ctx->qstart, ctx->scan_bsum, ctx->qm4, ctx->sp_in, ctx->sp_out, ctx->grid_info, ctx->grid_bounds, ctx->cell_start, ctx->t4, ctx->best_m, ctx->seed_m, ctx->st_dev, ctx->sorted.base, ctx->tkeys, ctx->tperm, ctx->qperm, ctx->bounds, ctx->sort_keys, ctx->sort_vals, ctx->sort_temp,
                  ctx->nrm.base, ctx->boxes, ctx->dec.base, ctx->tgt.base, ctx->src0.base, ctx->src.base, ctx->best,      ctx->seed,     ctx->idx,
-                 ctx->dist,     ctx->partial,   ctx->pcount,   ctx->red_out,   ctx->depth_dev, ctx->bp_counts};
+                 ctx->dist,     ctx->partial,   ctx->pcount,   ctx->red_out,   ctx->depth_dev, ctx->depth_flt, ctx->ks_buf, ctx->bp_counts};
   for (void* p : dev)
     if (p) (void)hipFree(p);
   if (ctx->red_host) (void)hipHostFree(ctx->red_host);
@@ -1598,8 +1598,19 @@ int icpk_align_batch_device(icpk_ctx* ctx, int32_t n_pairs, const icpk_pair* pai
   return align_batch_impl(ctx, n_pairs, pairs, p, T_out, stats, hipMemcpyDeviceToDevice);
 }
 
+struct DepthFilter {  // SLAM.cpp:553-574 filterDepthImage
+  int max_d, min_d, morph, ax, ay;
+};
+static int check_filter(icpk_ctx* ctx, int morph, int& ax, int& ay) {
+  if (ax < 0) ax = 2;  // cv::dilate / cv::erode default anchor (-1,-1): the element's centre
+  if (ay < 0) ay = 2;
+  if (morph != 0 && (ax > 4 || ay > 4)) return icpk_host_fail(ctx, ICPK_E_ARG, "anchor outside the 5x5 element");
+  return ICPK_OK;
+}
+
 static int backproject_impl(icpk_ctx* ctx, const uint16_t* depth, int32_t rows, int32_t cols, float fx, float cx,
-                            const float offset[3], int32_t which, int normals_mode /* <0: none */) {
+                            const float offset[3], int32_t which, int normals_mode /* <0: none */,
+                            const DepthFilter* flt = nullptr) {
   if (!ctx || !depth || rows <= 0 || cols <= 0 || (which != 0 && which != 1) || (int64_t)rows * cols > (1 << 28) ||
       normals_mode > ICPK_NORMALS_REFERENCE)
     return ICPK_E_ARG;
@@ -1610,6 +1621,9 @@ static int backproject_impl(icpk_ctx* ctx, const uint16_t* depth, int32_t rows, 
     ctx->depth_dev = nullptr;
     ctx->depth_cap = 0;
     ICPK_HIP(ctx, hipMalloc((void**)&ctx->depth_dev, (size_t)npix * sizeof(uint16_t)));
+    if (ctx->depth_flt) ICPK_HIP(ctx, hipFree(ctx->depth_flt));
+    ctx->depth_flt = nullptr;
+    ICPK_HIP(ctx, hipMalloc((void**)&ctx->depth_flt, (size_t)npix * sizeof(uint16_t)));
     ctx->depth_cap = npix;
   }
   const int nblocks = (npix + 1023) / 1024;
@@ -1624,6 +1638,12 @@ static int backproject_impl(icpk_ctx* ctx, const uint16_t* depth, int32_t rows, 
   int rc = ensure_cloud(ctx, c, npix);  // worst case: every pixel valid
   if (rc) return rc;
   ICPK_HIP(ctx, hipMemcpyAsync(ctx->depth_dev, depth, (size_t)npix * sizeof(uint16_t), hipMemcpyHostToDevice, ctx->stream));
+  const uint16_t* dimg = ctx->depth_dev;
+  if (flt) {  // SLAM.cpp:229,553-574: the frame is filtered before it is back-projected
+    launch_depth_filter(ctx->depth_dev, ctx->depth_flt, rows, cols, flt->min_d, flt->max_d, flt->ax, flt->ay, flt->morph,
+                        ctx->stream);
+    dimg = ctx->depth_flt;
+  }
   const float ox = offset ? offset[0] : 0.f, oy = offset ? offset[1] : 0.f, oz = offset ? offset[2] : 0.f;
   // the total lands in bp_counts[nblocks + 1] (device) and is read back pinned
   float *nxp = nullptr, *nyp = nullptr, *nzp = nullptr;
@@ -1634,7 +1654,7 @@ static int backproject_impl(icpk_ctx* ctx, const uint16_t* depth, int32_t rows, 
     nyp = ctx->nrm.y();
     nzp = ctx->nrm.z();
   }
-  launch_backproject(ctx->depth_dev, rows, cols, fx, cx, ox, oy, oz, c.x(), c.y(), c.z(), nxp, nyp, nzp,
+  launch_backproject(dimg, rows, cols, fx, cx, ox, oy, oz, c.x(), c.y(), c.z(), nxp, nyp, nzp,
                      normals_mode < 0 ? 0 : normals_mode, ctx->bp_counts, ctx->bp_counts + nblocks + 1, ctx->stream);
   ICPK_HIP(ctx, hipGetLastError());
   ICPK_HIP(ctx, hipMemcpyAsync(ctx->bp_n_host, ctx->bp_counts + nblocks + 1, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
@@ -1664,6 +1684,101 @@ static int backproject_impl(icpk_ctx* ctx, const uint16_t* depth, int32_t rows, 
   }
   ICPK_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return n;
+}
+
+int icpk_backproject_filtered(icpk_ctx* ctx, const uint16_t* depth, int32_t rows, int32_t cols, float fx, float cx,
+                              const float offset[3], int32_t which, int32_t normals_mode, int32_t max_d,
+                              int32_t min_d, int32_t morph, int32_t anchor_x, int32_t anchor_y) {
+  if (!ctx) return ICPK_E_ARG;
+  if (normals_mode >= 0 && which != 1) return icpk_host_fail(ctx, ICPK_E_ARG, "normals belong to the target cloud");
+  int ax = anchor_x, ay = anchor_y;
+  int rc = check_filter(ctx, morph, ax, ay);
+  if (rc) return rc;
+  const DepthFilter f{max_d, min_d, morph != 0, ax, ay};
+  return backproject_impl(ctx, depth, rows, cols, fx, cx, offset, which, normals_mode < 0 ? -1 : normals_mode, &f);
+}
+
+int icpk_filter_depth_image(icpk_ctx* ctx, const uint16_t* depth_in, uint16_t* depth_out, int32_t rows, int32_t cols,
+                            int32_t max_d, int32_t min_d, int32_t morph, int32_t anchor_x, int32_t anchor_y) {
+  if (!ctx || !depth_in || !depth_out || rows <= 0 || cols <= 0 || (int64_t)rows * cols > (1 << 28)) return ICPK_E_ARG;
+  int ax = anchor_x, ay = anchor_y;
+  int rc = check_filter(ctx, morph, ax, ay);
+  if (rc) return rc;
+  ICPK_HIP(ctx, hipSetDevice(ctx->device));
+  const int npix = rows * cols;
+  if (npix > ctx->depth_cap) {
+    if (ctx->depth_dev) ICPK_HIP(ctx, hipFree(ctx->depth_dev));
+    if (ctx->depth_flt) ICPK_HIP(ctx, hipFree(ctx->depth_flt));
+    ctx->depth_dev = ctx->depth_flt = nullptr;
+    ctx->depth_cap = 0;
+    ICPK_HIP(ctx, hipMalloc((void**)&ctx->depth_dev, (size_t)npix * sizeof(uint16_t)));
+    ICPK_HIP(ctx, hipMalloc((void**)&ctx->depth_flt, (size_t)npix * sizeof(uint16_t)));
+    ctx->depth_cap = npix;
+  }
+  ICPK_HIP(ctx, hipMemcpyAsync(ctx->depth_dev, depth_in, (size_t)npix * sizeof(uint16_t), hipMemcpyHostToDevice, ctx->stream));
+  launch_depth_filter(ctx->depth_dev, ctx->depth_flt, rows, cols, min_d, max_d, ax, ay, morph != 0, ctx->stream);
+  ICPK_HIP(ctx, hipGetLastError());
+  ICPK_HIP(ctx, hipMemcpyAsync(depth_out, ctx->depth_flt, (size_t)npix * sizeof(uint16_t), hipMemcpyDeviceToHost, ctx->stream));
+  ICPK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return ICPK_OK;
+}
+
+/* icp.cpp:488-515 on the context's clouds (source = the frame's key points, target = the map's) */
+int icpk_associate_keypoints(icpk_ctx* ctx, int32_t nn_mode, float max_dist, int32_t* assoc_query,
+                             int32_t* assoc_target, float* assoc_dist, int32_t* n_assoc, int32_t* rejected_query,
+                             int32_t rejected_capacity, int32_t* n_rejected) {
+  if (!ctx || !n_assoc || !n_rejected || *n_rejected < 0 || rejected_capacity < *n_rejected) return ICPK_E_ARG;
+  if (!ctx->have_tgt || !ctx->have_src) return icpk_host_fail(ctx, ICPK_E_NOT_SET, "source or target cloud not set");
+  // icp.cpp:490-491: an empty map returns BEFORE errors / associations are cleared: nothing is touched
+  if (ctx->tgt.n <= 0) return ICPK_W_EMPTY_MAP;
+  ICPK_HIP(ctx, hipSetDevice(ctx->device));
+  const int nq = ctx->src.n;
+  if (nq == 0) {  // icp.cpp:497-498: the lists are cleared, nothing is appended
+    *n_assoc = 0;
+    return ICPK_OK;
+  }
+  if (!assoc_query || !assoc_target || !assoc_dist || (!rejected_query && rejected_capacity > 0)) return ICPK_E_ARG;
+  int rc = enqueue_nn(ctx, nn_mode);
+  if (rc) return rc;
+  const int cap = round_up(nq, NN_TILE);
+  if (cap > ctx->ks_cap) {
+    if (ctx->ks_buf) ICPK_HIP(ctx, hipFree(ctx->ks_buf));
+    ctx->ks_buf = nullptr;
+    ctx->ks_cap = 0;
+    ICPK_HIP(ctx, hipMalloc((void**)&ctx->ks_buf, (size_t)4 * cap * sizeof(int32_t)));
+    ctx->ks_cap = cap;
+  }
+  const int nblocks = (nq + 1023) / 1024;
+  if (nblocks + 2 > ctx->bp_counts_cap) {
+    if (ctx->bp_counts) ICPK_HIP(ctx, hipFree(ctx->bp_counts));
+    ctx->bp_counts = nullptr;
+    ctx->bp_counts_cap = 0;
+    ICPK_HIP(ctx, hipMalloc((void**)&ctx->bp_counts, (size_t)(nblocks + 2) * sizeof(int)));
+    ctx->bp_counts_cap = nblocks + 2;
+  }
+  int32_t* dq = ctx->ks_buf;
+  int32_t* dt = dq + ctx->ks_cap;
+  float* dd = reinterpret_cast<float*>(dt + ctx->ks_cap);
+  int32_t* dr = dt + 2 * (size_t)ctx->ks_cap;
+  launch_assoc_split(ctx->best, nq, max_dist, ctx->bp_counts, ctx->bp_counts + nblocks + 1, dq, dt, dd, dr, ctx->stream);
+  ICPK_HIP(ctx, hipGetLastError());
+  ICPK_HIP(ctx, hipMemcpyAsync(ctx->bp_n_host, ctx->bp_counts + nblocks + 1, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  ICPK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  const int na = *ctx->bp_n_host, nr = nq - na;
+  if (*n_rejected + nr > rejected_capacity)
+    return icpk_host_fail(ctx, ICPK_E_ARG, "rejected_capacity too small for the appended queries");
+  if (na > 0) {
+    ICPK_HIP(ctx, hipMemcpyAsync(assoc_query, dq, (size_t)na * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    ICPK_HIP(ctx, hipMemcpyAsync(assoc_target, dt, (size_t)na * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    ICPK_HIP(ctx, hipMemcpyAsync(assoc_dist, dd, (size_t)na * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  }
+  if (nr > 0)
+    ICPK_HIP(ctx, hipMemcpyAsync(rejected_query + *n_rejected, dr, (size_t)nr * sizeof(int32_t), hipMemcpyDeviceToHost,
+                                 ctx->stream));
+  ICPK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  *n_assoc = na;           // icp.cpp:497-498: errors / associations are rebuilt by every call
+  *n_rejected += nr;       // icp.cpp:507-509: nonAssociations only ever grows
+  return ICPK_OK;
 }
 
 int icpk_backproject(icpk_ctx* ctx, const uint16_t* depth, int32_t rows, int32_t cols, float fx, float cx,

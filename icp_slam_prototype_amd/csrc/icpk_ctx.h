@@ -74,6 +74,9 @@ struct icpk_ctx {
   const int* stop = nullptr;     // &st_dev->done while a device loop is being enqueued, else null
   LoopState* st_active = nullptr;  // st_dev while a device loop is being enqueued, else null
   uint16_t* depth_dev = nullptr;
+  uint16_t* depth_flt = nullptr;  // filtered depth image (icpk_filter_depth_image / icpk_backproject_filtered)
+  int32_t* ks_buf = nullptr;      // key-point association lists: assoc_q | assoc_t | assoc_d | rej_q, ks_cap entries each
+  int ks_cap = 0;
   int depth_cap = 0;
   int* bp_counts = nullptr;
   int bp_counts_cap = 0;

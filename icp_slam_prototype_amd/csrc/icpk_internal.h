@@ -241,4 +241,13 @@ void launch_backproject(const uint16_t* depth, int rows, int cols, float fx, flo
                         float* x, float* y, float* z, float* nx, float* ny, float* nz, int normals_mode,
                         int* block_counts, int* n_out, hipStream_t s);
 
+// kernels_frontend.hip
+// order-preserving split of a sweep's result into accepted pairs and rejected queries
+// (icp.cpp:488-515); block_counts: ceil(nq/1024) + 1 ints of scratch, *n_accepted (device) = count
+void launch_assoc_split(const nn_key_t* best, int nq, float max_dist, int* block_counts, int* n_accepted,
+                        int32_t* assoc_q, int32_t* assoc_t, float* assoc_d, int32_t* rej_q, hipStream_t s);
+// SLAM.cpp:553-574: range clamp, then (morph != 0) 5x5 dilate + erode with anchor (ax, ay)
+void launch_depth_filter(const uint16_t* in, uint16_t* out, int rows, int cols, int min_d, int max_d, int ax, int ay,
+                         int morph, hipStream_t s);
+
 }  // namespace icpk

@@ -34,6 +34,8 @@ extern "C" {
 #define ICPK_OK 0
 #define ICPK_W_DEGENERATE 2       /* point-to-plane normal equations not positive definite:  \
                                     iteration stopped, transform so far returned            */
+#define ICPK_W_EMPTY_MAP 3       /* icpk_associate_keypoints with an empty target: outputs left \
+                                    untouched, as icp.cpp:490-491 returns before clearing them  */
 #define ICPK_W_TOO_FEW_PAIRS 1   /* < min_pairs associations: fell back to the  \
                                     caller's last motion (icp.cpp:163-182)      */
 #define ICPK_E_ARG (-1)          /* null pointer / negative size / bad enum     */
@@ -195,6 +197,21 @@ int icpk_transform_target(icpk_ctx *ctx, const float R[9], const float t[3]);
 /* associations of the last sweep (device -> host) */
 int icpk_get_associations(icpk_ctx *ctx, int32_t *idx_out, float *dist_out);
 
+/* icp.cpp:488-515 findGlobalKeyPointAssociations + :517-539 getNearestKeyPoint -- the LIVE
+ * association of the reference (icp.cpp:98,255) -- on the context's clouds: source = the frame's
+ * key points, target = the map's key points.  One NN sweep (same kernels as icpk_nn), then the
+ * order-preserving split on the device:
+ *   assoc_query / assoc_target / assoc_dist  [*n_assoc]  accepted pairs in query order
+ *       (`associations`, `errors`; rebuilt by every call, icp.cpp:497-498), accepted iff
+ *       dist < max_dist (MAX_NN_KEYPOINT_DISTANCE 0.1f, icp.hpp:10 / icp.cpp:503);
+ *   rejected_query [rejected_capacity]  the rejected query indices are APPENDED at *n_rejected,
+ *       which is in/out (`nonAssociations` is never cleared between sweeps, icp.cpp:507-509).
+ * Arrays need room for the source size.  Empty target: returns ICPK_W_EMPTY_MAP and touches
+ * nothing (icp.cpp:490-491).  Inside icpk_align the same acceptance is params.max_nn_dist. */
+int icpk_associate_keypoints(icpk_ctx *ctx, int32_t nn_mode, float max_dist, int32_t *assoc_query,
+                             int32_t *assoc_target, float *assoc_dist, int32_t *n_assoc,
+                             int32_t *rejected_query, int32_t rejected_capacity, int32_t *n_rejected);
+
 /* ---- whole loop: replaces icp.cpp:98-268 --------------------------------- */
 /* Starts from the source as uploaded (icpk_reset_source), leaves the aligned
  * source on the device.  T_out: row-major 4x4, same content as the CV_32FC1
@@ -263,6 +280,24 @@ int icpk_comm_barrier(icpk_ctx *ctx);
  * Returns the number of points (>= 0) or a negative status. */
 int icpk_backproject(icpk_ctx *ctx, const uint16_t *depth, int32_t rows, int32_t cols,
                      float fx, float cx, const float offset[3], int32_t which);
+
+/* SLAM.cpp:553-574 filterDepthImage on the device: every value outside [min_d, max_d] -> 0
+ * (:558-566; SLAM.cpp:229 passes 25000 / 1000, SLAM.hpp:15-16), then, if morph != 0, cv::dilate and
+ * cv::erode with the 5x5 rectangle of :568-573 in one LDS-tiled pass.  anchor_x / anchor_y: the
+ * anchor of dilate / erode inside the element, -1 = its centre (2, 2) -- what OpenCV uses when,
+ * as at :572-573, no anchor is passed (the Point(3,3) handed to getStructuringElement only shapes
+ * MORPH_CROSS elements).  OpenCV is third-party and absent here: anchor and border rule
+ * (out-of-image pixels never win) are PARITY UNPINNED, restated from its documentation.
+ * depth_in / depth_out: host arrays of rows x cols (may be the same array). */
+int icpk_filter_depth_image(icpk_ctx *ctx, const uint16_t *depth_in, uint16_t *depth_out, int32_t rows,
+                            int32_t cols, int32_t max_d, int32_t min_d, int32_t morph, int32_t anchor_x,
+                            int32_t anchor_y);
+/* filterDepthImage + back-projection without the image leaving the device (SLAM.cpp:229 then
+ * icp.cpp:38-39): as icpk_backproject (normals_mode < 0) or icpk_backproject_with_normals
+ * (normals_mode >= 0, which must be 1) on the filtered image */
+int icpk_backproject_filtered(icpk_ctx *ctx, const uint16_t *depth, int32_t rows, int32_t cols, float fx,
+                              float cx, const float offset[3], int32_t which, int32_t normals_mode,
+                              int32_t max_d, int32_t min_d, int32_t morph, int32_t anchor_x, int32_t anchor_y);
 
 /* ---- point-to-plane extension (BASELINE config 3; not in the reference) ---- */
 #define ICPK_NORMALS_CROSS 0     /* normalised cross product of back-projected central differences */

@@ -1,0 +1,165 @@
+"""The pieces either side of the loop on the GPU, through the
+C ABI, against the oracle: the key-point association lists of icp.cpp:488-539 (the reference's
+LIVE association variant) and filterDepthImage (SLAM.cpp:553-574: range clamp + 5x5 dilate /
+erode).  Index / integer work: bit-exact.
+
+The morphology's anchor and border rule follow OpenCV's documentation (OpenCV is absent here,
+and the reference holds no fixture): PARITY UNPINNED for those two rules -- the oracle and the
+kernel are two independent restatements of the same documented behaviour.
+
+/root/reference does not exist on the GPU box: nothing here reads it.
+"""
+import numpy as np
+import pytest
+
+from icp_slam_prototype_amd import binding, synth
+
+pytestmark = pytest.mark.gpu
+MODES = (binding.NN_EXACT, binding.NN_FILTERED, binding.NN_PRUNED, binding.NN_GRID)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from icp_slam_prototype_amd import build
+
+    build.build()
+    c = binding.Context(0)
+    yield c
+    c.close()
+
+
+# ----------------------------------------------------------------- key points --
+def _keypoint_clouds(rng, nq, nt):
+    """a few hundred frame key points against a few thousand map key points:
+    most queries sit within a few cm of a map point, the rest are far (rejected at 0.1 f)"""
+    tgt = (rng.uniform(-2, 2, (3, nt)) + 5).astype(np.float32)
+    pick = rng.integers(0, nt, nq)
+    src = tgt[:, pick] + rng.normal(0, 0.04, (3, nq)).astype(np.float32)
+    far = rng.random(nq) < 0.3
+    src[:, far] += rng.uniform(0.3, 1.0, (3, int(far.sum()))).astype(np.float32)
+    return src.astype(np.float32), tgt
+
+
+@pytest.mark.parametrize("nq,nt", [(200, 1000), (800, 5000), (431, 2777), (1, 1), (3000, 64)])
+def test_keypoint_associations_match_oracle(ctx, oracle, nq, nt):
+    rng = np.random.default_rng(nq * 31 + nt)
+    src, tgt = _keypoint_clouds(rng, nq, nt)
+    want = oracle.keypoint_associations(src, tgt, 0.1)
+    assert 0 < len(want[0]) < nq or nq == 1
+    for mode in MODES:
+        ctx.set_target(tgt)
+        ctx.set_source(src)
+        rc, aq, at, ad, rj = ctx.associate_keypoints(0.1, mode)
+        assert rc == 0
+        assert np.array_equal(aq, want[0]) and np.array_equal(at, want[1])
+        assert np.array_equal(ad.view(np.uint32), want[2].view(np.uint32))
+        assert np.array_equal(rj, want[3])  # rejected queries in query order (icp.cpp:507-509)
+        assert len(aq) + len(rj) == nq
+
+
+def test_keypoint_rejected_list_is_appended_and_empty_map_touches_nothing(ctx, oracle):
+    rng = np.random.default_rng(9)
+    src, tgt = _keypoint_clouds(rng, 500, 3000)
+    ctx.set_target(tgt)
+    ctx.set_source(src)
+    # two sweeps (icp.cpp:98 and :255 share one nonAssociations list that is never cleared)
+    rc, aq1, at1, ad1, rj1 = ctx.associate_keypoints()
+    R = oracle.make_rotation_matrix(0.5, -0.3, 0.2)
+    t = np.array([0.01, 0.02, -0.01], np.float32)
+    ctx.transform_source(R, t)
+    rc, aq2, at2, ad2, rj2 = ctx.associate_keypoints(rejected=rj1)
+    o1 = oracle.keypoint_associations(src, tgt, 0.1)
+    o2 = oracle.keypoint_associations(oracle.transform_points(src, R, t), tgt, 0.1, rejected=o1[3])
+    assert np.array_equal(rj1, o1[3]) and np.array_equal(rj2, o2[3]) and len(rj2) > len(rj1)
+    assert np.array_equal(rj2[:len(rj1)], rj1)
+    assert np.array_equal(aq2, o2[0]) and np.array_equal(at2, o2[1]) and np.array_equal(ad2.view(np.uint32), o2[2].view(np.uint32))
+    # a capacity that cannot take the appended queries is refused before anything is written
+    with pytest.raises(binding.IcpkError) as e:
+        ctx.associate_keypoints(rejected=rj1, capacity=len(rj1) + 1)
+    assert e.value.code == binding.E_ARG
+    # empty map: icp.cpp:490-491 returns before errors / associations are cleared
+    ctx.set_target(np.zeros((3, 0), np.float32))
+    rc, aq, at, ad, rj = ctx.associate_keypoints(rejected=rj2)
+    assert rc == binding.W_EMPTY_MAP and aq is None and np.array_equal(rj, rj2)
+    assert oracle.keypoint_associations(src, np.zeros((3, 0), np.float32), 0.1) is None
+    # no key points in the frame: the lists are cleared, nothing is appended
+    ctx.set_target(tgt)
+    ctx.set_source(np.zeros((3, 0), np.float32))
+    rc, aq, at, ad, rj = ctx.associate_keypoints(rejected=rj2)
+    assert rc == 0 and len(aq) == 0 and np.array_equal(rj, rj2)
+    # threshold semantics: strict '<' on the float distance, NaN never accepted
+    tgt1 = np.array([[0.0], [0.0], [0.0]], np.float32)
+    src1 = np.array([[0.1, np.nextafter(np.float32(0.1), np.float32(0)), np.nan], [0, 0, 0], [0, 0, 0]], np.float32)
+    ctx.set_target(tgt1)
+    ctx.set_source(src1)
+    rc, aq, at, ad, rj = ctx.associate_keypoints(np.float32(0.1), binding.NN_EXACT)
+    assert list(aq) == [1] and list(rj) == [0, 2]
+
+
+def test_align_with_keypoint_threshold_matches_oracle(ctx, oracle):
+    """the loop on key-point sized clouds with MAX_NN_KEYPOINT_DISTANCE (icp.cpp:98,255; icp.hpp:10)"""
+    rng = np.random.default_rng(4)
+    src, tgt = _keypoint_clouds(rng, 600, 4000)
+    ctx.set_target(tgt)
+    ctx.set_source(src)
+    T, st, rc = ctx.align(max_nn_dist=0.1, max_iterations=6, fixed_iterations=1)
+    o = oracle.align(src, tgt, max_iterations=6, max_nn_dist=0.1, solve=0, sum_order=1, fixed_iterations=True)
+    assert st.final_pairs == o["final_pairs"] and 0 < st.final_pairs < 600
+    assert np.array_equal(ctx.get_associations()[0], o["idx"])
+    assert np.linalg.norm(T.astype(np.float64) - o["T"].astype(np.float64)) < 1e-5
+
+
+# --------------------------------------------------------------- depth filter --
+def _depth_image(rng, rows, cols):
+    d = rng.integers(0, 30000, (rows, cols)).astype(np.uint16)
+    d[rng.random((rows, cols)) < 0.2] = 0                      # holes
+    d[rng.random((rows, cols)) < 0.05] = 65535                 # saturated
+    yy, xx = np.mgrid[0:rows, 0:cols]
+    smooth = (9000 + 40 * yy + 25 * xx).astype(np.uint16)      # a wall: neighbours differ little
+    keep = rng.random((rows, cols)) < 0.5
+    return np.where(keep, smooth, d).astype(np.uint16)
+
+
+@pytest.mark.parametrize("rows,cols", [(480, 640), (424, 512), (37, 53), (1, 1), (5, 200), (16, 64), (17, 65), (3, 3)])
+def test_filter_depth_image_bit_exact(ctx, oracle, rows, cols):
+    rng = np.random.default_rng(rows * 1000 + cols)
+    d = _depth_image(rng, rows, cols)
+    for anchor in ((-1, -1), (2, 2), (3, 3), (0, 0), (4, 1)):
+        a = (2, 2) if anchor == (-1, -1) else anchor
+        got = ctx.filter_depth_image(d, 25000, 1000, True, anchor)
+        want = oracle.filter_depth_image(d, 25000, 1000, a)
+        assert np.array_equal(got, want), (anchor, int(np.count_nonzero(got != want)))
+    # range clamp alone (SLAM.cpp:558-566), odd limits
+    for max_d, min_d in ((25000, 1000), (9000, 9000), (70000, -5), (-1, 0)):
+        got = ctx.filter_depth_image(d, max_d, min_d, False)
+        assert np.array_equal(got, oracle.depth_range_filter(d, max_d, min_d).reshape(rows, cols))
+    with pytest.raises(binding.IcpkError):
+        ctx.filter_depth_image(d, anchor=(5, 2))
+
+
+def test_filter_closes_small_holes_and_is_idempotent_on_flat_walls(ctx):
+    """what the reference wants from it (SLAM.cpp:551-552: mask noisy edges, close holes): a 5x5
+    closing fills holes narrower than 5 px inside a flat wall and leaves the wall itself alone"""
+    d = np.full((60, 80), 10000, np.uint16)
+    d[20:23, 30:34] = 0        # a 3 x 4 hole
+    d[40:48, 10:18] = 0        # an 8 x 8 hole survives (shrunk by nothing: closing is extensive)
+    out = ctx.filter_depth_image(d)
+    assert (out[20:23, 30:34] == 10000).all()
+    assert (out[42:46, 12:16] == 0).all()
+    assert np.array_equal(ctx.filter_depth_image(out), out)  # closing is idempotent
+
+
+def test_backproject_filtered_equals_filter_then_backproject(ctx, oracle):
+    p = synth.kinect_pair(240, 320, valid=0.7, seed=12)
+    d = p["depth_src"].copy()
+    d[::7, ::5] = 40000  # beyond maxDistance
+    n = ctx.backproject_filtered(d, which=0, offset=[5, 5, 5])
+    want = oracle.backproject(oracle.filter_depth_image(d)) + np.float32(5)
+    assert n == want.shape[1]
+    ctx.set_target(p["target"])  # (the working source needs a target only for the checks of get_source)
+    assert np.array_equal(ctx.get_source(), want.astype(np.float32))
+    # clamp only, into the target, with normals
+    n = ctx.backproject_filtered(d, which=1, normals_mode=binding.NORMALS_CROSS, morph=False)
+    f = oracle.depth_range_filter(d).reshape(d.shape)
+    pts, nrm = oracle.backproject_normals(f, 0)
+    assert n == pts.shape[1] and np.array_equal(ctx.get_target(), pts) and np.array_equal(ctx.get_target_normals(), nrm)
