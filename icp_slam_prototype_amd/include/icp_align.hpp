@@ -2,6 +2,11 @@
 //
 // Mirrors the reference's operator surface for the ICP path without OpenCV:
 //   * icp::align(source, target, params, &result)      -- the inner loop on SoA views
+//     (north_star's call surface; runs on the calling thread's default Engine, or pass one)
+//   * icp::alignBatch(engine, pairs, params, results)  -- frame-batch mode
+//   * icp::Comm                                        -- RCCL collectives of the multi-GPU modes
+//   * icp::filterDepthImage / icp::findGlobalKeyPointAssociations -- SLAM.cpp:553-574,
+//     icp.cpp:488-515 with the reference's names and argument meaning
 //   * icp::Tracker                                     -- the per-frame state machine of
 //     icp::getTransformation (icp.cpp:22-26 file-scope pose state, :38-71 cloud set-up,
 //     :98-268 loop, :237/:246 pose update), fed with raw CV_16UC1 depth buffers
@@ -14,9 +19,11 @@
 // is usable -- there is no CPU fallback).
 #pragma once
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "icpk.h"
@@ -74,6 +81,134 @@ inline int align(Engine& eng, const CloudView& source, const CloudView& target, 
   }
   out->status = icpk_align(eng.ctx(), &params, out->T, &out->stats);
   return out->status;
+}
+
+// north_star's call surface: align(source, target, params, &result) on the calling thread's
+// default Engine (device ICPK_DEVICE or 0; created on first use; one per host thread, as one
+// context serialises its calls).  Throws std::runtime_error on first use if no GPU is usable.
+inline Engine& defaultEngine() {
+  static thread_local Engine eng([] {
+    const char* e = std::getenv("ICPK_DEVICE");
+    return e ? std::atoi(e) : 0;
+  }());
+  return eng;
+}
+inline int align(const CloudView& source, const CloudView& target, const AlignParams& params, AlignResult* out) {
+  return align(defaultEngine(), source, target, params, out);
+}
+
+// Frame-batch mode (BASELINE config 4): independent pairs, lock-step groups on the
+// engine's GPU (icpk_align_batch).  results is resized to pairs.size(); returns the first
+// negative status, else the largest.
+struct FramePair {
+  CloudView source, target;
+};
+inline int alignBatch(Engine& eng, const std::vector<FramePair>& pairs, const AlignParams& params,
+                      std::vector<AlignResult>* results) {
+  if (!results) return ICPK_E_ARG;
+  const size_t n = pairs.size();
+  std::vector<icpk_pair> raw(n);
+  for (size_t k = 0; k < n; ++k) {
+    raw[k] = icpk_pair{pairs[k].source.x, pairs[k].source.y, pairs[k].source.z, pairs[k].source.n,
+                       pairs[k].target.x, pairs[k].target.y, pairs[k].target.z, pairs[k].target.n, nullptr, nullptr};
+  }
+  std::vector<float> T(16 * (n ? n : 1));
+  std::vector<icpk_stats> st(n ? n : 1);
+  const int rc = icpk_align_batch(eng.ctx(), (int32_t)n, raw.data(), &params, T.data(), st.data());
+  results->resize(n);
+  for (size_t k = 0; k < n; ++k) {
+    std::memcpy((*results)[k].T, T.data() + 16 * k, sizeof((*results)[k].T));
+    (*results)[k].stats = st[k];
+    (*results)[k].status = st[k].status;
+  }
+  return rc;
+}
+
+// RCCL collectives of the multi-GPU modes on an Engine (icpk_comm_* of icpk.h): one process or
+// host thread + one Engine per GPU; the 128-byte id made by rank 0 (Comm::uniqueId) reaches the
+// other ranks by the host's own means.
+class Comm {
+ public:
+  static int uniqueId(unsigned char id[ICPK_COMM_ID_BYTES]) { return icpk_comm_unique_id(id); }
+  Comm(Engine& eng, const unsigned char id[ICPK_COMM_ID_BYTES], int rank, int world) : eng_(eng) {
+    status = icpk_comm_init_rccl(eng.ctx(), id, rank, world);
+  }
+  ~Comm() { icpk_comm_destroy(eng_.ctx()); }
+  Comm(const Comm&) = delete;
+  Comm& operator=(const Comm&) = delete;
+  int rank() const { return icpk_comm_rank(eng_.ctx()); }
+  int world() const { return icpk_comm_world(eng_.ctx()); }
+  // this rank's block [start, start + count) of n_items
+  void partition(int32_t n_items, int32_t* start, int32_t* count) const {
+    icpk_comm_partition(n_items, world(), rank(), start, count);
+  }
+  int broadcastTarget(int root = 0) { return icpk_comm_broadcast_target(eng_.ctx(), root); }
+  // local: this rank's block of results; all: resized to n_total, global pair order
+  int gatherResults(const std::vector<AlignResult>& local, int32_t n_total, std::vector<AlignResult>* all) {
+    if (!all) return ICPK_E_ARG;
+    std::vector<float> Tl(16 * (local.size() ? local.size() : 1)), Ta(16 * (size_t)(n_total > 0 ? n_total : 1)),
+        Sa(4 * (size_t)(n_total > 0 ? n_total : 1));
+    std::vector<icpk_stats> sl(local.size() ? local.size() : 1);
+    for (size_t k = 0; k < local.size(); ++k) {
+      std::memcpy(Tl.data() + 16 * k, local[k].T, 16 * sizeof(float));
+      sl[k] = local[k].stats;
+      sl[k].status = local[k].status;
+    }
+    const int rc = icpk_comm_gather_results(eng_.ctx(), Tl.data(), sl.data(), (int32_t)local.size(), n_total, Ta.data(),
+                                            Sa.data());
+    if (rc != ICPK_OK) return rc;
+    all->assign((size_t)n_total, AlignResult{});
+    for (int32_t k = 0; k < n_total; ++k) {
+      AlignResult& r = (*all)[(size_t)k];
+      std::memcpy(r.T, Ta.data() + 16 * (size_t)k, 16 * sizeof(float));
+      r.stats.iterations = (int32_t)Sa[4 * (size_t)k];
+      r.status = r.stats.status = (int32_t)Sa[4 * (size_t)k + 1];
+      r.stats.final_pairs = (int32_t)Sa[4 * (size_t)k + 2];
+      r.stats.final_mse = Sa[4 * (size_t)k + 3];
+    }
+    return ICPK_OK;
+  }
+  int status = ICPK_OK;
+
+ private:
+  Engine& eng_;
+};
+
+// SLAM.cpp:553-574 (SLAM.hpp:34): filterDepthImage(image, rgbImage, maxDistance, minDistance) on a
+// CV_16UC1 buffer, in place; the colour image is not touched by the reference either
+inline int filterDepthImage(Engine& eng, uint16_t* image, int rows, int cols, int maxDistance = 25000,
+                            int minDistance = 1000) {
+  return icpk_filter_depth_image(eng.ctx(), image, image, rows, cols, maxDistance, minDistance, 1, -1, -1);
+}
+
+// icp.cpp:488-515: data key points vs map key points.  errors / associations are rebuilt (pairs of
+// (query index, nearest index) in query order), nonAssociations is appended to; an empty map
+// returns ICPK_W_EMPTY_MAP and touches nothing (icp.cpp:490-491).
+inline int findGlobalKeyPointAssociations(Engine& eng, const CloudView& dataKeypoints, const CloudView& mapKeypoints,
+                                          std::vector<float>& errors,
+                                          std::vector<std::pair<int32_t, int32_t>>& associations,
+                                          std::vector<int32_t>& nonAssociations,
+                                          float maxDistance = ICPK_MAX_NN_KEYPOINT_DISTANCE) {
+  if (mapKeypoints.n <= 0) return ICPK_W_EMPTY_MAP;
+  int rc = icpk_set_target(eng.ctx(), mapKeypoints.x, mapKeypoints.y, mapKeypoints.z, mapKeypoints.n);
+  if (rc == ICPK_OK) rc = icpk_set_source(eng.ctx(), dataKeypoints.x, dataKeypoints.y, dataKeypoints.z, dataKeypoints.n);
+  if (rc != ICPK_OK) return rc;
+  const size_t nq = (size_t)(dataKeypoints.n > 0 ? dataKeypoints.n : 0), had = nonAssociations.size();
+  std::vector<int32_t> q(nq + 1), t(nq + 1);
+  std::vector<float> d(nq + 1);
+  nonAssociations.resize(had + nq);
+  int32_t na = 0, nr = (int32_t)had;
+  rc = icpk_associate_keypoints(eng.ctx(), ICPK_NN_GRID, maxDistance, q.data(), t.data(), d.data(), &na,
+                                nonAssociations.data(), (int32_t)nonAssociations.size(), &nr);
+  if (rc != ICPK_OK) {
+    nonAssociations.resize(had);
+    return rc;
+  }
+  nonAssociations.resize((size_t)nr);
+  errors.assign(d.begin(), d.begin() + na);
+  associations.clear();
+  for (int32_t k = 0; k < na; ++k) associations.emplace_back(q[(size_t)k], t[(size_t)k]);
+  return ICPK_OK;
 }
 
 // icp.cpp:640-653

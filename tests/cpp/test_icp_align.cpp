@@ -6,9 +6,16 @@
 //   test_icp_align <in.bin> <out.bin>
 // in : int32 rows, cols, nframes, max_iter; float threshold; uint16 depth[nframes][rows*cols]
 // out: per frame pair i=1..nframes-1: int32 status, iterations; float T[16], camR[9], camP[3]
-//      then icp::align on (frame1 cloud, frame0 cloud given as SoA after the depth data):
+//      then icp::align on (frame1 cloud, frame0 cloud given as SoA after the depth data): int32
+//      status, iterations; float T[16]; then the same pair three times through icp::alignBatch and
+//      through the engine-less icp::align(source, target, params, &result): int32 agree (1/0);
+//      then the gathered copy of the batch through icp::Comm with world = 1: int32 agree;
+//      then frame 0 through icp::filterDepthImage: uint16[rows*cols];
+//      then icp::findGlobalKeyPointAssociations(source as key points, target as map, 0.1):
+//      int32 status, n_assoc, n_rejected; int32 pairs[2*n_assoc]; float errors[n_assoc]; int32 rejected[n_rejected]
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "icp_align.hpp"
@@ -68,6 +75,47 @@ int main(int argc, char** argv) {
       const int32_t head[2] = {rc, r.stats.iterations};
       std::fwrite(head, 4, 2, o);
       std::fwrite(r.T, 4, 16, o);
+      // frame-batch mode and north_star's engine-less call surface give the same bits
+      std::vector<icp::FramePair> pairs(3, icp::FramePair{src, tgt});
+      std::vector<icp::AlignResult> br;
+      const int brc = icp::alignBatch(eng, pairs, p, &br);
+      icp::AlignResult r2;
+      const int rc2 = icp::align(src, tgt, p, &r2);
+      int32_t agree = brc == rc && rc2 == rc && br.size() == 3;
+      for (const auto& b : br)
+        agree = agree && std::memcmp(b.T, r.T, sizeof(r.T)) == 0 && b.stats.iterations == r.stats.iterations;
+      agree = agree && std::memcmp(r2.T, r.T, sizeof(r.T)) == 0;
+      std::fwrite(&agree, 4, 1, o);
+      // RCCL behind the C ABI from C++ (world of one): gathered rows == local rows
+      unsigned char id[ICPK_COMM_ID_BYTES];
+      int32_t cagree = icp::Comm::uniqueId(id) == ICPK_OK;
+      if (cagree) {
+        icp::Comm comm(eng, id, 0, 1);
+        std::vector<icp::AlignResult> all;
+        int32_t s0 = -1, c0 = -1;
+        comm.partition(3, &s0, &c0);
+        cagree = comm.status == ICPK_OK && comm.world() == 1 && s0 == 0 && c0 == 3 &&
+                 comm.gatherResults(br, 3, &all) == ICPK_OK && all.size() == 3;
+        for (size_t k = 0; cagree && k < 3; ++k)
+          cagree = std::memcmp(all[k].T, br[k].T, sizeof(r.T)) == 0 && all[k].stats.iterations == br[k].stats.iterations &&
+                   all[k].stats.final_pairs == br[k].stats.final_pairs;
+      }
+      std::fwrite(&cagree, 4, 1, o);
+      std::vector<uint16_t> img = frames[0];
+      if (icp::filterDepthImage(eng, img.data(), rows, cols) != ICPK_OK) return 10;
+      std::fwrite(img.data(), 2, img.size(), o);
+      std::vector<float> errors;
+      std::vector<std::pair<int32_t, int32_t>> assoc;
+      std::vector<int32_t> rejected;
+      const int krc = icp::findGlobalKeyPointAssociations(eng, src, tgt, errors, assoc, rejected);
+      const int32_t kh[3] = {krc, (int32_t)assoc.size(), (int32_t)rejected.size()};
+      std::fwrite(kh, 4, 3, o);
+      for (const auto& a : assoc) {
+        const int32_t pr[2] = {a.first, a.second};
+        std::fwrite(pr, 4, 2, o);
+      }
+      std::fwrite(errors.data(), 4, errors.size(), o);
+      std::fwrite(rejected.data(), 4, rejected.size(), o);
     }
   } catch (const std::exception& e) {
     std::fprintf(stderr, "%s\n", e.what());

@@ -74,3 +74,26 @@ def test_tracker_sequence_and_align(oracle):
     o = oracle.align(p["source"], p["target"], max_iterations=max_iter, solve=1, sum_order=1, fixed_iterations=True,
                      threads=4)
     assert rc == 0 and iters == max_iter and np.linalg.norm(T.astype(np.float64) - o["T"].astype(np.float64)) < 1e-6
+    off += 4 * 16
+    # icp::alignBatch x3 and the engine-less icp::align(source, target, params, &result) == icp::align
+    agree, cagree = struct.unpack_from("<2i", raw, off)
+    off += 8
+    assert agree == 1, "frame-batch / default-engine results differ from icp::align"
+    assert cagree == 1, "icp::Comm (RCCL, world of one) did not return the local rows"
+    # icp::filterDepthImage (SLAM.cpp:553-574) vs the oracle
+    img = np.frombuffer(raw, np.uint16, rows * cols, off).reshape(rows, cols)
+    off += 2 * rows * cols
+    assert np.array_equal(img, oracle.filter_depth_image(frames[0]))
+    # icp::findGlobalKeyPointAssociations (icp.cpp:488-515) vs the oracle
+    krc, na, nr = struct.unpack_from("<3i", raw, off)
+    off += 12
+    pairs = np.frombuffer(raw, np.int32, 2 * na, off).reshape(na, 2)
+    off += 8 * na
+    errors = np.frombuffer(raw, np.float32, na, off)
+    off += 4 * na
+    rejected = np.frombuffer(raw, np.int32, nr, off)
+    off += 4 * nr
+    want = oracle.keypoint_associations(p["source"], p["target"], 0.1)
+    assert krc == 0 and np.array_equal(pairs[:, 0], want[0]) and np.array_equal(pairs[:, 1], want[1])
+    assert np.array_equal(errors.view(np.uint32), want[2].view(np.uint32)) and np.array_equal(rejected, want[3])
+    assert off == len(raw)
