@@ -162,14 +162,19 @@ def cpu_baseline_child(workload):
         idx, dist = o.nn_bruteforce(sub, tgt, threads=th)
         return time.perf_counter() - t0, idx, dist
 
-    # calibrate the sample so that one sample takes ~2.5 s
+    # calibrate: one sample = `rounds` sweeps of m queries and lasts ~2.5 s
     sweep(min(256, nq), threads)  # warm-up (thread team, caches)
     t_cal, _, _ = sweep(min(2048, nq), threads)
-    m = int(min(nq, max(2048, 2048 * 2.5 / max(t_cal, 1e-4))))
+    want = 2048 * 2.5 / max(t_cal, 1e-4)          # queries per 2.5 s
+    m = int(min(nq, max(2048, want)))
+    rounds = max(1, int(round(want / m)))
     samples = []
     for _ in range(5):
-        t, idx, dist = sweep(m, threads)
-        samples.append(t * nq / m)
+        tt = 0.0
+        for _r in range(rounds):
+            t, idx, dist = sweep(m, threads)
+            tt += t
+        samples.append(tt / rounds * nq / m)
     t_nn = statistics.median(samples)
     # one thread: cost per pair of the scalar scan (BASELINE.md B1 stand-in)
     t1_cal, _, _ = sweep(min(128, nq), 1)
@@ -192,7 +197,8 @@ def cpu_baseline_child(workload):
         "value": it_s, "unit": "iter/s", "cores": threads, "kind": "port",
         "sample": f"median of 5 NN sweeps of {m} of {nq} queries x {nt} targets on {threads} pinned OpenMP threads "
                   f"(OMP_PROC_BIND={os.environ.get('OMP_PROC_BIND')}, OMP_PLACES={os.environ.get('OMP_PLACES')}; "
-                  f"each sample {t_nn * m / nq:.1f} s, scaled linearly to Nq; spread {spread * 100:.1f} %) + median of 3 "
+                  f"each sample = {rounds} such sweep(s), {t_nn * m / nq * rounds:.1f} s, scaled linearly to Nq; spread "
+                  f"{spread * 100:.1f} %) + median of 3 "
                   f"full reduce/solve/transform; oracle/icp_oracle.c, gcc -O2",
         "nn_s_per_sweep": t_nn, "gpairs_per_s": nq * float(nt) / t_nn / 1e9, "sample_spread": spread,
         "one_thread_ns_per_pair": ns_per_pair_1t,
@@ -243,7 +249,14 @@ def roofline_blocks(workload, nn_mode, nq, nt, avg_nn_s, timing, kernel):
             phys["valu_issue_note"] = ("SQ_INSTS_VALU per launch / (1024 SIMDs x 1.2 G wave-instructions/s x launch time): "
                                        "the fp32 issue bound; f64 and sqrt instructions issue 2-4x slower, so the true "
                                        "issue occupancy is higher")
-        phys["binds"] = e.get("binds", "neither roofline: per-wave latency / instruction issue")
+        vf = phys.get("valu_issue_frac") or 0.0
+        if max(vf, phys["frac"]) < 0.5:
+            phys["binds"] = ("neither bound binds alone: dependent memory phases per wave + instruction issue "
+                             f"(HBM {phys['frac'] * 100:.0f} %, VALU issue >= {vf * 100:.0f} %)")
+        elif vf >= phys["frac"]:
+            phys["binds"] = f"VALU instruction issue (>= {vf * 100:.0f} % of the fp32 issue bound; HBM {phys['frac'] * 100:.1f} %)"
+        else:
+            phys["binds"] = f"HBM ({phys['frac'] * 100:.0f} %)"
     yard = {"bound": "hbm", "achieved": alg_bytes / avg_nn_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": alg_bytes / avg_nn_s / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": alg_bytes,
             "gpairs_per_s_kernel": nq * float(nt) / avg_nn_s / 1e9,
