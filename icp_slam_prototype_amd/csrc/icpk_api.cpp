@@ -252,7 +252,7 @@ int prepare_grid_target(icpk_ctx* ctx) {
   rc = ensure_scan_buffers(ctx);
   if (rc) return rc;
   launch_grid_bounds(ctx->tgt.x(), ctx->tgt.y(), ctx->tgt.z(), nt, ctx->grid_bounds, ctx->stream);
-  launch_grid_info(ctx->grid_bounds, nt, ctx->grid_ppc, ctx->grid_info, ctx->stream);
+  launch_grid_info(ctx->grid_bounds, nt, ctx->grid_ppc, ctx->grid_xdiv, ctx->grid_info, ctx->stream);
   // counting sort of the targets by cell: slot within the cell by atomics (the order inside a
   // cell is irrelevant: candidates are merged lexicographically), cell starts by an exclusive
   // scan of the counts (entry ncells = Nt), scatter into the AoS copy
@@ -619,6 +619,7 @@ static icpk_ctx* make_context(int device_id, const icpk_ctx* parent) {
     ctx->target_blocks = parent->target_blocks;
     ctx->slices = parent->slices;
     ctx->grid_ppc = parent->grid_ppc;
+    ctx->grid_xdiv = parent->grid_xdiv;
     ctx->grid_slices = parent->grid_slices;
     ctx->q_per_lane = parent->q_per_lane;
   }
@@ -646,6 +647,10 @@ int icpk_create(icpk_ctx** out, int device_id) {
   if (const char* e = std::getenv("ICPK_GRID_PPC")) {
     const float v = (float)std::atof(e);
     if (v > 0.f) ctx->grid_ppc = v;
+  }
+  if (const char* e = std::getenv("ICPK_GRID_XDIV")) {
+    const int v = std::atoi(e);
+    if (v >= 1 && v <= 64) ctx->grid_xdiv = v;
   }
   if (const char* e = std::getenv("ICPK_GRID_SLICES")) {
     const int v = std::atoi(e);

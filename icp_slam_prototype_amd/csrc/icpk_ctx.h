@@ -116,6 +116,7 @@ struct icpk_ctx {
   bool grid_chain = false;   // device loop only: the previous sweep was a grid sweep (qm4 / sp_in current)
   int t4_cap = 0;
   bool have_grid = false;  // grid matches tgt
+  int grid_xdiv = 4;       // cells are this many times finer along x (ICPK_GRID_XDIV; measured best on config 2: 4)
   float grid_ppc = 6.f;    // aimed-at targets per occupied cell (measured best on config 2: 6)
   int grid_slices = 0;     // lanes per query (0 = by cloud size)
   std::string err;

@@ -103,13 +103,15 @@ constexpr int GRID_MAX_CELLS = 1 << 22;
 constexpr int GRID_BOUNDS_PARTS = 256;  // partial boxes of the bounds pass (6 floats each)
 struct GridInfo {
   float lo[3];  // finite lower corner of the target
-  float inv_h;  // 1 / cell edge
+  float inv_h;  // 1 / cell edge (y and z)
   float h;
+  float inv_hx;  // 1 / cell edge along x = xdiv / h
+  int xdiv;
   int nx, ny, nz;
   int ncells;
 };
 void launch_grid_bounds(const float* x, const float* y, const float* z, int n, float* fb, hipStream_t s);
-void launch_grid_info(const float* fb, int n, float ppc, GridInfo* g, hipStream_t s);
+void launch_grid_info(const float* fb, int n, float ppc, int xdiv, GridInfo* g, hipStream_t s);
 void launch_grid_tscatter(const float* x, const float* y, const float* z, const int* tcell, const int* tslot,
                           const int* cell_start, int n, float4* t4, hipStream_t s);
 void launch_grid_qslot(const float* x, const float* y, const float* z, int n, const GridInfo* g, int* count, int* qcell,

@@ -64,7 +64,10 @@ __global__ __launch_bounds__(1024) void grid_bounds_kernel(const float* __restri
 // cell edge: about `ppc` targets per occupied cell if the cloud is a surface whose area is
 // of the order of the bounding box's faces (a depth image is); never more than
 // GRID_MAX_CELLS cells.  Only efficiency depends on the choice.
-__global__ void grid_info_kernel(const float* __restrict__ fbp, int nparts, int n, float ppc,
+// Cells are `xdiv` times finer along x, the axis the sorted order runs along: a query's cube
+// costs one contiguous range per (y, z) row whatever the x resolution, so finer x cells trim
+// the ranges to the cube (fewer candidates outside it) at no extra look-up.
+__global__ void grid_info_kernel(const float* __restrict__ fbp, int nparts, int n, float ppc, int xdiv,
                                  GridInfo* __restrict__ g) {
   // one wave: lane l merges the partial boxes l, l + 64, ...; xor butterfly; lane 0 goes on
   float fb[6];
@@ -96,8 +99,10 @@ __global__ void grid_info_kernel(const float* __restrict__ fbp, int nparts, int 
   h = __builtin_fmaxf(h, emax / 1023.f);  // <= 1024 cells per axis
   h = __builtin_fmaxf(h, 1e-30f);
   int nx, ny, nz;
+  float hx;
   for (;;) {
-    nx = (int)(ext[0] / h) + 1;
+    hx = h / (float)xdiv;
+    nx = (int)(ext[0] / hx) + 1;
     ny = (int)(ext[1] / h) + 1;
     nz = (int)(ext[2] / h) + 1;
     if ((long long)nx * ny * nz <= GRID_MAX_CELLS) break;
@@ -108,6 +113,8 @@ __global__ void grid_info_kernel(const float* __restrict__ fbp, int nparts, int 
   g->lo[2] = lo[2];
   g->h = h;
   g->inv_h = 1.0f / h;
+  g->inv_hx = 1.0f / hx;
+  g->xdiv = xdiv;
   g->nx = nx;
   g->ny = ny;
   g->nz = nz;
@@ -134,7 +141,7 @@ __global__ void grid_qslot_kernel(const float* __restrict__ x, const float* __re
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const GridInfo g = *gi;
-  const int cx = grid_cell(x[i], g.lo[0], g.inv_h, g.nx);
+  const int cx = grid_cell(x[i], g.lo[0], g.inv_hx, g.nx);
   const int cy = grid_cell(y[i], g.lo[1], g.inv_h, g.ny);
   const int cz = grid_cell(z[i], g.lo[2], g.inv_h, g.nz);
   const int c = (cz * g.ny + cy) * g.nx + cx;
@@ -302,8 +309,8 @@ int grid_bounds_parts(int n) {  // one 1024-thread block per 2048 points, at mos
 void launch_grid_bounds(const float* x, const float* y, const float* z, int n, float* fb, hipStream_t s) {
   hipLaunchKernelGGL(grid_bounds_kernel, dim3(grid_bounds_parts(n)), dim3(1024), 0, s, x, y, z, n, fb);
 }
-void launch_grid_info(const float* fb, int n, float ppc, GridInfo* g, hipStream_t s) {
-  hipLaunchKernelGGL(grid_info_kernel, dim3(1), dim3(64), 0, s, fb, grid_bounds_parts(n), n, ppc, g);
+void launch_grid_info(const float* fb, int n, float ppc, int xdiv, GridInfo* g, hipStream_t s) {
+  hipLaunchKernelGGL(grid_info_kernel, dim3(1), dim3(64), 0, s, fb, grid_bounds_parts(n), n, ppc, xdiv < 1 ? 1 : xdiv, g);
 }
 
 // ---- the sweep --------------------------------------------------------------------------
@@ -331,10 +338,14 @@ __device__ __forceinline__ void cube_cells(float q, float r, float lo, float inv
 // (100 MHz) stamps of the phases and work counters.
 #ifdef ICPK_GRID_STAMPS
 __device__ unsigned long long grid_dbg[8 * 16384];
+#ifdef ICPK_GRID_COUNTS  // counters only: the slots hold counts, no time stamps
+#define GRID_STAMP(k)
+#else
 #define GRID_STAMP(k)                                                                         \
   do {                                                                                        \
     if ((threadIdx.x & 63) == 0 && wave_id < 16384) grid_dbg[wave_id * 8 + (k)] = wall_clock64(); \
   } while (0)
+#endif
 #ifdef ICPK_GRID_COUNTS
 #define GRID_COUNT(k, v)                                                                      \
   do {                                                                                        \
@@ -546,27 +557,27 @@ __device__ __forceinline__ void nn_grid_body(
   GRID_STAMP(2);
   if constexpr (!EXPAND) {
     int x0, x1, y0, y1, z0, z1;
-    cube_cells(qx, bd, g.lo[0], g.inv_h, g.nx, x0, x1);
+    cube_cells(qx, bd, g.lo[0], g.inv_hx, g.nx, x0, x1);
     cube_cells(qy, bd, g.lo[1], g.inv_h, g.ny, y0, y1);
     cube_cells(qz, bd, g.lo[2], g.inv_h, g.nz, z0, z1);
     scan_cells(x0, x1, y0, y1, z0, z1);
     share();
   } else {
-    const int cx = grid_cell(qx, g.lo[0], g.inv_h, g.nx);
+    const int cx = grid_cell(qx, g.lo[0], g.inv_hx, g.nx);
     const int cy = grid_cell(qy, g.lo[1], g.inv_h, g.ny);
     const int cz = grid_cell(qz, g.lo[2], g.inv_h, g.nz);
     bool active = scan;
     for (int R = 1; __builtin_amdgcn_ballot_w64(active) != 0; R = R < (1 << 20) ? 2 * R : R) {
       int X0, X1, Y0, Y1, Z0, Z1;
-      cube_cells(qx, bd, g.lo[0], g.inv_h, g.nx, X0, X1);
+      cube_cells(qx, bd, g.lo[0], g.inv_hx, g.nx, X0, X1);
       cube_cells(qy, bd, g.lo[1], g.inv_h, g.ny, Y0, Y1);
       cube_cells(qz, bd, g.lo[2], g.inv_h, g.nz, Z0, Z1);
-      const int x0 = max(X0, cx - R), x1 = min(X1, cx + R);
+      const int x0 = max(X0, cx - R * g.xdiv), x1 = min(X1, cx + R * g.xdiv);  // the same physical reach on every axis
       const int y0 = max(Y0, cy - R), y1 = min(Y1, cy + R);
       const int z0 = max(Z0, cz - R), z1 = min(Z1, cz + R);
       if (active) scan_cells(x0, x1, y0, y1, z0, z1);
       share();
-      cube_cells(qx, bd, g.lo[0], g.inv_h, g.nx, X0, X1);
+      cube_cells(qx, bd, g.lo[0], g.inv_hx, g.nx, X0, X1);
       cube_cells(qy, bd, g.lo[1], g.inv_h, g.ny, Y0, Y1);
       cube_cells(qz, bd, g.lo[2], g.inv_h, g.nz, Z0, Z1);
       active = active && !(X0 >= x0 && X1 <= x1 && Y0 >= y0 && Y1 <= y1 && Z0 >= z0 && Z1 <= z1);
