@@ -258,10 +258,10 @@ int prepare_grid_target(icpk_ctx* ctx) {
   // scan of the counts (entry ncells = Nt), scatter into the AoS copy
   int* tcell = reinterpret_cast<int*>(ctx->sort_keys + ctx->sort_cap);
   int* tslot = ctx->sort_vals;
-  launch_grid_zero_counts(ctx->qcount, ctx->grid_info, ctx->stream);
-  launch_grid_qslot(ctx->tgt.x(), ctx->tgt.y(), ctx->tgt.z(), nt, ctx->grid_info, ctx->qcount, tcell, tslot,
+  launch_grid_zero_counts(ctx->qcount, ctx->grid_info, 0, ctx->stream);
+  launch_grid_qslot(ctx->tgt.x(), ctx->tgt.y(), ctx->tgt.z(), nt, ctx->grid_info, ctx->qcount, tcell, tslot, 0,
                     ctx->stream);
-  launch_grid_scan(ctx->qcount, ctx->cell_start, ctx->scan_bsum, ctx->grid_info, ctx->stream);
+  launch_grid_scan(ctx->qcount, ctx->cell_start, ctx->scan_bsum, ctx->grid_info, 0, ctx->stream);
   launch_grid_tscatter(ctx->tgt.x(), ctx->tgt.y(), ctx->tgt.z(), tcell, tslot, ctx->cell_start, nt, ctx->t4,
                        ctx->stream);
   ICPK_HIP(ctx, hipGetLastError());
@@ -278,10 +278,11 @@ int enqueue_cell_order(icpk_ctx* ctx) {
   if (rc) return rc;
   int* qcell = reinterpret_cast<int*>(ctx->sort_keys + ctx->sort_cap);
   int* qslot = ctx->sort_vals;
-  launch_grid_zero_counts(ctx->qcount, ctx->grid_info, ctx->stream);
-  launch_grid_qslot(ctx->src.x(), ctx->src.y(), ctx->src.z(), nq, ctx->grid_info, ctx->qcount, qcell, qslot,
+  // (locality only: the coarser table, xdiv times fewer counts to zero and scan)
+  launch_grid_zero_counts(ctx->qcount, ctx->grid_info, 1, ctx->stream);
+  launch_grid_qslot(ctx->src.x(), ctx->src.y(), ctx->src.z(), nq, ctx->grid_info, ctx->qcount, qcell, qslot, 1,
                     ctx->stream);
-  launch_grid_scan(ctx->qcount, ctx->qstart, ctx->scan_bsum, ctx->grid_info, ctx->stream);
+  launch_grid_scan(ctx->qcount, ctx->qstart, ctx->scan_bsum, ctx->grid_info, 1, ctx->stream);
   launch_grid_qscatter(qcell, qslot, ctx->qstart, nq, ctx->qperm, ctx->stream);
   ICPK_HIP(ctx, hipGetLastError());
   return ICPK_OK;

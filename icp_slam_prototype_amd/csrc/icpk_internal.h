@@ -109,17 +109,19 @@ struct GridInfo {
   int xdiv;
   int nx, ny, nz;
   int ncells;
+  int nxq;       // cells along x of the coarser grid that orders the queries (nx / xdiv)
+  int ncells_q;
 };
 void launch_grid_bounds(const float* x, const float* y, const float* z, int n, float* fb, hipStream_t s);
 void launch_grid_info(const float* fb, int n, float ppc, int xdiv, GridInfo* g, hipStream_t s);
 void launch_grid_tscatter(const float* x, const float* y, const float* z, const int* tcell, const int* tslot,
                           const int* cell_start, int n, float4* t4, hipStream_t s);
 void launch_grid_qslot(const float* x, const float* y, const float* z, int n, const GridInfo* g, int* count, int* qcell,
-                       int* qslot, hipStream_t s);
+                       int* qslot, int coarse, hipStream_t s);
 void launch_grid_qscatter(const int* qcell, const int* qslot, const int* qstart, int n, int* qperm, hipStream_t s);
 constexpr int GRID_SCAN_BLOCKS = (GRID_MAX_CELLS + 1 + 2047) / 2048 + 1;  // scratch ints of launch_grid_scan
-void launch_grid_zero_counts(int* count, const GridInfo* g, hipStream_t s);
-void launch_grid_scan(const int* in, int* out, int* bsum, const GridInfo* g, hipStream_t s);
+void launch_grid_zero_counts(int* count, const GridInfo* g, int coarse, hipStream_t s);
+void launch_grid_scan(const int* in, int* out, int* bsum, const GridInfo* g, int coarse, hipStream_t s);
 // one pair's arguments of a grid sweep (K1d); see nn_grid_body
 struct GridSweepArgs {
   float *qx, *qy, *qz;  // the caller's source planes (kept in step when K3 is fused)

@@ -119,6 +119,9 @@ __global__ void grid_info_kernel(const float* __restrict__ fbp, int nparts, int 
   g->ny = ny;
   g->nz = nz;
   g->ncells = nx * ny * nz;
+  // the query order (locality only) uses cells xdiv times coarser along x: a shorter count table
+  g->nxq = (nx + xdiv - 1) / xdiv;
+  g->ncells_q = g->nxq * ny * nz;
 }
 
 // The ONE mapping coordinate -> cell index along an axis, used for targets and for the
@@ -137,14 +140,15 @@ __device__ __forceinline__ int grid_cell(float v, float lo, float inv_h, int n) 
 // matters for locality (results are scattered back by original index).
 __global__ void grid_qslot_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                   const float* __restrict__ z, int n, const GridInfo* __restrict__ gi,
-                                  int* __restrict__ count, int* __restrict__ qcell, int* __restrict__ qslot) {
+                                  int* __restrict__ count, int* __restrict__ qcell, int* __restrict__ qslot,
+                                  int coarse) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const GridInfo g = *gi;
   const int cx = grid_cell(x[i], g.lo[0], g.inv_hx, g.nx);
   const int cy = grid_cell(y[i], g.lo[1], g.inv_h, g.ny);
   const int cz = grid_cell(z[i], g.lo[2], g.inv_h, g.nz);
-  const int c = (cz * g.ny + cy) * g.nx + cx;
+  const int c = coarse ? (cz * g.ny + cy) * g.nxq + cx / g.xdiv : (cz * g.ny + cy) * g.nx + cx;
   qcell[i] = c;
   qslot[i] = atomicAdd(&count[c], 1);
 }
@@ -166,9 +170,13 @@ constexpr int GSCAN_ITEMS = 8;
 constexpr int GSCAN_TILE = 256 * GSCAN_ITEMS;
 constexpr int GSCAN_MAX_BLOCKS = (GRID_MAX_CELLS + 1 + GSCAN_TILE - 1) / GSCAN_TILE;  // 2049
 
+__device__ __forceinline__ int grid_table_size(const GridInfo* __restrict__ gi, int coarse) {
+  return (coarse ? gi->ncells_q : gi->ncells) + 1;
+}
+
 __global__ __launch_bounds__(256) void grid_zero_counts_kernel(int* __restrict__ count,
-                                                               const GridInfo* __restrict__ gi) {
-  const int n = gi->ncells + 1;
+                                                               const GridInfo* __restrict__ gi, int coarse) {
+  const int n = grid_table_size(gi, coarse);
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) count[i] = 0;
 }
 
@@ -184,9 +192,9 @@ __device__ __forceinline__ int block_sum_256(int v, int* sh) {  // sum over the 
 
 __global__ __launch_bounds__(256) void grid_scan_sums_kernel(const int* __restrict__ in,
                                                              const GridInfo* __restrict__ gi,
-                                                             int* __restrict__ bsum) {
+                                                             int* __restrict__ bsum, int coarse) {
   __shared__ int sh[4];
-  const int n = gi->ncells + 1;
+  const int n = grid_table_size(gi, coarse);
   const int base = blockIdx.x * GSCAN_TILE;
   if (base >= n) return;
   int v = 0;
@@ -200,10 +208,10 @@ __global__ __launch_bounds__(256) void grid_scan_sums_kernel(const int* __restri
 }
 
 __global__ __launch_bounds__(1024) void grid_scan_offsets_kernel(int* __restrict__ bsum,
-                                                                 const GridInfo* __restrict__ gi) {
+                                                                 const GridInfo* __restrict__ gi, int coarse) {
   // exclusive scan of the nb <= 2049 block sums in place: 3 per lane, wave scan, 16 wave totals
   __shared__ int wtot[16];
-  const int n = gi->ncells + 1;
+  const int n = grid_table_size(gi, coarse);
   const int nb = (n + GSCAN_TILE - 1) / GSCAN_TILE;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   int a[3], s = 0;
@@ -234,9 +242,10 @@ __global__ __launch_bounds__(1024) void grid_scan_offsets_kernel(int* __restrict
 
 __global__ __launch_bounds__(256) void grid_scan_apply_kernel(const int* __restrict__ in,
                                                               const GridInfo* __restrict__ gi,
-                                                              const int* __restrict__ boff, int* __restrict__ out) {
+                                                              const int* __restrict__ boff, int* __restrict__ out,
+                                                              int coarse) {
   __shared__ int wtot[4];
-  const int n = gi->ncells + 1;
+  const int n = grid_table_size(gi, coarse);
   const int base = blockIdx.x * GSCAN_TILE;
   if (base >= n) return;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -266,14 +275,15 @@ __global__ __launch_bounds__(256) void grid_scan_apply_kernel(const int* __restr
   }
 }
 
-void launch_grid_zero_counts(int* count, const GridInfo* g, hipStream_t s) {
-  hipLaunchKernelGGL(grid_zero_counts_kernel, dim3(512), dim3(256), 0, s, count, g);
+// coarse = 1: the table of the query order (ncells_q entries), else the targets' (ncells)
+void launch_grid_zero_counts(int* count, const GridInfo* g, int coarse, hipStream_t s) {
+  hipLaunchKernelGGL(grid_zero_counts_kernel, dim3(512), dim3(256), 0, s, count, g, coarse);
 }
-// out[i] = sum of in[0 .. i) for i in [0, ncells]; bsum: GRID_SCAN_BLOCKS ints of scratch
-void launch_grid_scan(const int* in, int* out, int* bsum, const GridInfo* g, hipStream_t s) {
-  hipLaunchKernelGGL(grid_scan_sums_kernel, dim3(GSCAN_MAX_BLOCKS), dim3(256), 0, s, in, g, bsum);
-  hipLaunchKernelGGL(grid_scan_offsets_kernel, dim3(1), dim3(1024), 0, s, bsum, g);
-  hipLaunchKernelGGL(grid_scan_apply_kernel, dim3(GSCAN_MAX_BLOCKS), dim3(256), 0, s, in, g, bsum, out);
+// out[i] = sum of in[0 .. i) for i in [0, size]; bsum: GRID_SCAN_BLOCKS ints of scratch
+void launch_grid_scan(const int* in, int* out, int* bsum, const GridInfo* g, int coarse, hipStream_t s) {
+  hipLaunchKernelGGL(grid_scan_sums_kernel, dim3(GSCAN_MAX_BLOCKS), dim3(256), 0, s, in, g, bsum, coarse);
+  hipLaunchKernelGGL(grid_scan_offsets_kernel, dim3(1), dim3(1024), 0, s, bsum, g, coarse);
+  hipLaunchKernelGGL(grid_scan_apply_kernel, dim3(GSCAN_MAX_BLOCKS), dim3(256), 0, s, in, g, bsum, out, coarse);
 }
 
 // targets into the AoS copy (x, y, z, original index), one 16-byte load per candidate
@@ -293,9 +303,10 @@ void launch_grid_tscatter(const float* x, const float* y, const float* z, const 
 }
 
 void launch_grid_qslot(const float* x, const float* y, const float* z, int n, const GridInfo* g, int* count, int* qcell,
-                       int* qslot, hipStream_t s) {
+                       int* qslot, int coarse, hipStream_t s) {
   if (n <= 0) return;
-  hipLaunchKernelGGL(grid_qslot_kernel, dim3((n + 255) / 256), dim3(256), 0, s, x, y, z, n, g, count, qcell, qslot);
+  hipLaunchKernelGGL(grid_qslot_kernel, dim3((n + 255) / 256), dim3(256), 0, s, x, y, z, n, g, count, qcell, qslot,
+                     coarse);
 }
 void launch_grid_qscatter(const int* qcell, const int* qslot, const int* qstart, int n, int* qperm, hipStream_t s) {
   if (n <= 0) return;
