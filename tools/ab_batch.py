@@ -2,15 +2,24 @@
 lock-step batch of config-2 pairs (device resident).  usage: python tools/ab_batch.py [-DFLAG ...]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import torch
-torch.cuda.init()
+if "--build-only" not in sys.argv:
+    import torch
+    torch.cuda.init()
 import numpy as np
 from icp_slam_prototype_amd import build, binding, synth
 
 flags = [a for a in sys.argv[1:] if a.startswith("-D")]
 tag = "_".join(f[2:].replace("=", "") for f in flags) or "base"
-os.makedirs(f"/tmp/icpk_{tag}", exist_ok=True)
-binding.LIB_PATH = build.build(force=True, extra=flags, out=f"/tmp/icpk_{tag}/libicpk.so")
+# variants are built where the snapshot travels from (build them in the container, run on the GPU box)
+vdir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "icp_slam_prototype_amd", "lib_variants", tag)
+os.makedirs(vdir, exist_ok=True)
+vlib = os.path.join(vdir, "libicpk.so")
+if flags and not os.path.exists(vlib):
+    build.build(force=True, extra=flags, out=vlib)
+if flags:
+    binding.LIB_PATH = vlib
+if "--build-only" in sys.argv:
+    sys.exit(0)
 n = int(os.environ.get("PAIRS", 16))
 dev = []
 for k in range(n):
