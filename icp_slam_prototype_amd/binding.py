@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libicpk.so")
+LIB_PATH = os.environ.get("ICPK_LIB_PATH") or os.path.join(HERE, "lib", "libicpk.so")  # (ICPK_LIB_PATH: a diagnostic variant build)
 
 OK = 0
 W_TOO_FEW_PAIRS = 1

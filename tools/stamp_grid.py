@@ -32,6 +32,8 @@ for first in (True, False):
     print("  wave end ns: " + " ".join(f"p{int(q*100)} {np.quantile(en, q):.0f}" for q in (0.5, 0.9, 0.99, 0.999, 1.0)))
     tot = (b[:, 4] - b[:, 0]) * 10.0
     print(f"  busy fraction of {7 * 1024} slots x span: {tot.sum() / (7 * 1024 * en.max()):.2f}")
+    dec = np.array_split(np.arange(len(b)), 10)
+    print("  wave duration by decile of block index (us):", " ".join(f"{tot[d].mean() / 1e3:.1f}/{tot[d].max() / 1e3:.1f}" for d in dec))
     st = (b[:, 0] - t0) * 10.0
     print(f"  wave start ns: p50 {np.median(st):.0f} p90 {np.quantile(st, 0.9):.0f} max {st.max():.0f}")
 
