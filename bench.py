@@ -165,7 +165,8 @@ def cpu_baseline_child(workload):
     # calibrate: one sample = `rounds` sweeps of m queries and lasts ~2.5 s
     sweep(min(256, nq), threads)  # warm-up (thread team, caches)
     t_cal, _, _ = sweep(min(2048, nq), threads)
-    want = 2048 * 2.5 / max(t_cal, 1e-4)          # queries per 2.5 s
+    sample_s = float(os.environ.get("ICPK_CPU_SAMPLE_S", "2.5"))  # seconds per sample (tests shorten it)
+    want = 2048 * sample_s / max(t_cal, 1e-4)     # queries per sample
     m = int(min(nq, max(2048, want)))
     rounds = max(1, int(round(want / m)))
     samples = []
@@ -178,7 +179,7 @@ def cpu_baseline_child(workload):
     t_nn = statistics.median(samples)
     # one thread: cost per pair of the scalar scan (BASELINE.md B1 stand-in)
     t1_cal, _, _ = sweep(min(128, nq), 1)
-    m1 = int(min(nq, max(128, 128 * 2.0 / max(t1_cal, 1e-4))))
+    m1 = int(min(nq, max(128, 128 * 0.8 * sample_s / max(t1_cal, 1e-4))))
     t1, _, _ = sweep(m1, 1)
     ns_per_pair_1t = t1 / (float(m1) * nt) * 1e9
     idx_full = np.resize(idx, nq)

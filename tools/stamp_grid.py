@@ -34,6 +34,20 @@ for first in (True, False):
     print(f"  busy fraction of {7 * 1024} slots x span: {tot.sum() / (7 * 1024 * en.max()):.2f}")
     dec = np.array_split(np.arange(len(b)), 10)
     print("  wave duration by decile of block index (us):", " ".join(f"{tot[d].mean() / 1e3:.1f}/{tot[d].max() / 1e3:.1f}" for d in dec))
+    # list scheduling of the measured wave durations over the wave slots: what a heaviest-first start
+    # order could buy (durations taken as fixed, which they are not quite: they include queueing)
+    import heapq
+    def span(order, slots=7 * 1024):
+        free = [0.0] * slots
+        heapq.heapify(free)
+        end = 0.0
+        for w in order:
+            t = heapq.heappop(free) + tot[w]
+            end = max(end, t)
+            heapq.heappush(free, t)
+        return end / 1e3
+    print(f"  simulated span (us): natural order {span(range(len(tot))):.1f}, heaviest first {span(np.argsort(-tot)):.1f}, "
+          f"lightest first {span(np.argsort(tot)):.1f}, lower bound {tot.sum() / (7 * 1024) / 1e3:.1f}")
     st = (b[:, 0] - t0) * 10.0
     print(f"  wave start ns: p50 {np.median(st):.0f} p90 {np.quantile(st, 0.9):.0f} max {st.max():.0f}")
 
