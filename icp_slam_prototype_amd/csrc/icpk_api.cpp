@@ -377,8 +377,9 @@ int prepare_sorted_sweep(icpk_ctx* ctx, int nn_mode, NnArgs& a, NnBoxes& bx, int
   return ICPK_OK;
 }
 
-// lanes per query of the grid scan (measured: 8 is best from 10k to 307k queries, 4 at 10^6)
-int grid_slices_for(const icpk_ctx* ctx, int nq) { return ctx->grid_slices ? ctx->grid_slices : (nq > 500000 ? 4 : 8); }
+// lanes per query of the grid scan (measured with cells 4x finer along x: 8 is best up to 217k queries, 4 from
+// 307k on; a launch that fills the GPU several times over is issue-bound and prefers fewer, longer lanes)
+int grid_slices_for(const icpk_ctx* ctx, int nq) { return ctx->grid_slices ? ctx->grid_slices : (nq > 262144 ? 4 : 8); }
 
 // the K1d arguments of the sweep prepare_sorted_sweep has just set up, and the bookkeeping
 // that follows its launch
