@@ -1,0 +1,36 @@
+"""bench.py's N > 1 path (BASELINE configs[3]: pairs block-partitioned over one process per GPU,
+results all-gathered every step) rehearsed on the one GPU of this box: two ranks share cuda:0 and
+the collectives run over gloo (ICPK_BENCH_REHEARSAL=1; RCCL refuses two ranks on one device).  Keeps
+the launch contract -- `python -m torch.distributed.run ... bench.py --gpus N`, one JSON line from
+rank 0 -- from rotting between the driver's 8-GPU runs."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_two_rank_frame_batch_line():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, ICPK_BENCH_REHEARSAL="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+           "--batch-pairs", "6"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]  # ONE JSON line, from rank 0
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 1 and d["unit"] == "iter/s" and d["value"] > 0
+    assert d["scaling"] == "strong" and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert d["config"]["frame_pairs_per_step"] == 6 and d["config"]["pairs_per_gpu"] == 3
+    assert d["results_consistent_on_all_ranks"] is True
+    assert d["collectives"].startswith("torch.distributed(gloo")
