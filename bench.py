@@ -430,13 +430,21 @@ def frame_batch_one_gpu(args, torch, dev, gpu_index, single_value):
         torch.cuda.synchronize()
         each.append(time.perf_counter() - t0)
     dt = statistics.median(each)
-    ctx.close()
     total_iters = sum(s.iterations for s in st)
+    # PCIe-inclusive (never a headline): the same call with HOST buffers, as the reference would hand them
+    # over (icpk_align_batch: every cloud crosses PCIe from pageable memory inside the call); 16 pairs
+    nh = min(16, args.batch_pairs)
+    host_pairs = [(s.cpu().numpy(), t.cpu().numpy()) for s, t in keep[:nh]]
+    ctx.align_batch(host_pairs, params)
+    t0 = time.perf_counter()
+    Th, sth, rch = ctx.align_batch(host_pairs, params)
+    pcie_rate = sum(s.iterations for s in sth) / (time.perf_counter() - t0)
+    ctx.close()
     return {"workload": f"{args.batch_pairs} distinct config-2 pairs (seeds {BATCH_SEED0}..{BATCH_SEED0 + args.batch_pairs - 1}), "
                         f"{args.iters} fixed iterations each, resident in HBM, icpk_align_batch_device on ONE GPU "
                         f"(lock-step groups of {os.environ.get('ICPK_BATCH_GROUP', '16')})",
             "value": total_iters / dt, "unit": "iter/s", "ms_per_batch": dt * 1e3, "ms_per_pair": dt * 1e3 / args.batch_pairs,
-            "vs_single_pair": total_iters / dt / single_value, "reps": reps, "timing": "median of 5 calls, host wall clock, "
+            "vs_single_pair": total_iters / dt / single_value, "pcie_inclusive_iter_s": pcie_rate, "reps": reps, "timing": "median of 5 calls, host wall clock, "
             "device idle before and after each call", "ms_each": [round(t * 1e3, 3) for t in each]}
 
 
