@@ -33,6 +33,7 @@ groups on its GPU, no per-iteration collective; one RCCL all-gather of the resul
 aggregate iterations/s; total work is fixed, so "scaling" is "strong".
 """
 import argparse
+import gc
 import json
 import os
 import statistics
@@ -287,6 +288,8 @@ def timed_alignments(torch, ctx, params, steps, warmup, sync_all):
         ctx.align(params)
     params.profile = 1
     params.profile_stride = params.max_iterations + 1
+    gc.collect()
+    gc.disable()  # a generation-2 collection of the interpreter (tens of ms) must not land in the timed region
     sync_all()
     t0 = time.perf_counter()
     nn_ms = 0.0
@@ -299,6 +302,7 @@ def timed_alignments(torch, ctx, params, steps, warmup, sync_all):
         iters_done += st.iterations
     sync_all()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     return elapsed, iters_done, nn_launches, nn_timed, nn_ms
 
 
@@ -418,17 +422,20 @@ def frame_batch_one_gpu(args, torch, dev, gpu_index, single_value):
     keep, pargs = batch_pairs_on_device(torch, dev, range(args.batch_pairs))
     ctx = binding.Context(gpu_index)
     params = binding.default_params(max_iterations=args.iters, fixed_iterations=1)
-    for _ in range(3):  # warm-up: allocates the slots; the runtime's pools settle within the first calls
+    for _ in range(2):  # warm-up: the first call allocates the slots
         T, st, rc = ctx.align_batch_device(pargs, params)
     assert rc == 0 and all(s.iterations == args.iters for s in st)
     reps = 5
     each = []
+    gc.collect()
+    gc.disable()
     for _ in range(reps):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         T, st, rc = ctx.align_batch_device(pargs, params)
         torch.cuda.synchronize()
         each.append(time.perf_counter() - t0)
+    gc.enable()
     dt = statistics.median(each)
     total_iters = sum(s.iterations for s in st)
     # PCIe-inclusive (never a headline): the same call with HOST buffers, as the reference would hand them
@@ -513,16 +520,18 @@ def bench_frame_batch(args, torch, dist, rank, world, dev, cdev, gpu_index, rehe
             Tg, Sg = comm.gather_results(T, batch.stats_rows(st), n_pairs)
         return rc, Tg, Sg
 
-    for _ in range(3):  # set-up, before the W warm-up steps: the slots are allocated by the first call
-        step()          # and the runtime's pools settle within the first three calls of a process
+    step()  # set-up, before the W warm-up steps: the first call allocates the slots
     for _ in range(args.warmup):
         step()
+    gc.collect()
+    gc.disable()  # (the interpreter's generation-2 collections take tens of ms: several steps of this workload)
     sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         rc, Tg, Sg = step()
     sync_all()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     tt = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     elapsed = float(tt.item())

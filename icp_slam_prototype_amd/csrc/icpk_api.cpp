@@ -1586,10 +1586,13 @@ int align_batch_impl(icpk_ctx* ctx, int32_t n_pairs, const icpk_pair* pairs, con
     prev = g;
     have_prev = true;
   }
+  const auto te0 = now();
   if (have_prev) finish_group(prev);
+  const auto te1 = now();
   // host input buffers were read asynchronously: everything has landed before we return
   ICPK_HIP(ctx, hipStreamSynchronize(ctx->stream));
   for (icpk_ctx* sl : ctx->slots) ICPK_HIP(ctx, hipStreamSynchronize(sl->stream));
+  if (trace) std::fprintf(stderr, "icpk batch tail: wait+finish last group %.0f us, stream syncs %.0f us\n", us(te0, te1), us(te1, now()));
   return worst;
 }
 
