@@ -154,6 +154,7 @@ __device__ __forceinline__ void loop_step_body(const double* __restrict__ partia
     float M[9], Rinv[9];
     for (int k = 0; k < 9; ++k) M[k] = (float)sums[k];  // icp.cpp:212
     solve_reference(M, Rrec);                           // icp.cpp:215-223
+    STEP_STAMP(i, 5);
     if (i == 0) {
       for (int k = 0; k < 9; ++k) st->Trot[k] = Rrec[k];  // icp.cpp:227-229
     } else {

@@ -10,13 +10,13 @@ p = synth.kinect_pair(480, 640, valid=0.30, seed=2)
 ctx = binding.Context(0)
 ctx.set_target(p["target"]); ctx.set_source(p["source"])
 L = binding.load()
-for solve in (binding.SOLVE_REFERENCE, binding.SOLVE_KABSCH):
+for solve in (binding.SOLVE_REFERENCE,):
     for _ in range(3):
         ctx.align(max_iterations=20, fixed_iterations=1, solve=solve)
     buf = np.zeros(8 * 64, np.uint64)
     L.icpk_debug_read_step_stamps(buf.ctypes.data_as(C.POINTER(C.c_ulonglong)))
     b = buf.reshape(64, 8).astype(np.int64)[:20]
-    for name, a, c in (("stage2", 0, 1), ("control", 1, 2), ("solve", 2, 3), ("store", 3, 4), ("total", 0, 4)):
+    for name, a, c in (("stage2", 0, 1), ("control", 1, 2), ("solve", 2, 3), ("  polar", 2, 5), ("  rest", 5, 3), ("store", 3, 4), ("total", 0, 4)):
         v = (b[:, c] - b[:, a]) * 10.0
         print(f"solve={solve} {name:8s} ns: mean {v.mean():8.0f} min {v.min():8.0f} max {v.max():8.0f}")
     print("step-to-step period ns:", np.diff(b[:, 0]).mean() * 10.0)
