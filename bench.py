@@ -406,6 +406,7 @@ def bench_single(args, torch, dev, gpu_index):
         out["extra"] = {}
         for name, iters, steps in (("kinect640x480_dense", 20, 10), ("dense1m", 50, 4)):
             out["extra"][f"{name}_{iters}iters"] = extra_workload(args, torch, dev, gpu_index, name, iters, steps)
+        out["extra"]["tracker_path"] = tracker_path(gpu_index)
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.workload)
         if "value" in out["cpu_baseline"]:
@@ -477,6 +478,54 @@ def extra_workload(args, torch, dev, gpu_index, name, iters, steps):
     return {"workload": f"{name}: {nq} x {nt} points, {iters} fixed iterations per step, {steps} steps",
             "value": iters_done / elapsed, "unit": "iter/s", "ms_per_step": elapsed / steps * 1e3,
             "nn_mpoints_per_s": nn_launches * nq / elapsed / 1e6, "roofline": phys, "roofline_algorithmic": yard}
+
+
+def tracker_path(gpu_index):
+    """The callers either side of the loop as SLAM.cpp drives them --
+    icp::Tracker::getTransformation's call sequence through the C ABI: per frame pair two 640x480
+    uint16 depth images cross PCIe, are back-projected on the device (with and without
+    filterDepthImage), posed, aligned with the reference's own settings (16 iterations at most,
+    threshold 1e-4, SLAM.cpp:277) and the per-iteration trace is read back.  PCIe-inclusive by
+    nature; frame pairs per second."""
+    from icp_slam_prototype_amd import binding, synth
+
+    rng = np.random.default_rng(0)
+    frames = []
+    for k in range(6):
+        d = synth.render_room_depth(480, 640, synth.rot_xyz_deg(0, 0.5 * k, 0), np.array([0.01 * k, 0, 0]),
+                                    noise_sigma=0.002, rng=rng)
+        d[rng.random(d.shape) > 0.3] = 0
+        frames.append(d.astype(np.uint16))
+    ctx = binding.Context(gpu_index)
+    camR, camP = np.eye(3, dtype=np.float32), np.full(3, 5, np.float32)
+    res = {}
+    for filt in (False, True):
+        def pair(prev, cur):
+            for d, w in ((prev, 1), (cur, 0)):
+                ctx.backproject_filtered(d, which=w) if filt else ctx.backproject(d, which=w)
+            ctx.transform_target(camR, camP)
+            ctx.transform_source(camR, camP)
+            ctx.commit_source()
+            T, st, rc = ctx.align(max_iterations=16, threshold=1e-4)
+            ctx.get_trace(16)
+            return st
+
+        for i in range(1, len(frames)):
+            pair(frames[i - 1], frames[i])
+        t0 = time.perf_counter()
+        n = its = 0
+        for _ in range(4):
+            for i in range(1, len(frames)):
+                its += pair(frames[i - 1], frames[i]).iterations
+                n += 1
+        dt = time.perf_counter() - t0
+        res["with_filterDepthImage" if filt else "plain"] = {
+            "frame_pairs_per_s": n / dt, "ms_per_pair": dt / n * 1e3, "mean_iterations": its / n,
+            "points": [ctx.source_size, ctx.target_size]}
+    ctx.close()
+    res["workload"] = ("6 synthetic 640x480 frames (30 % valid, camera drifting 0.5 degree / 1 cm per frame), consecutive pairs, "
+                       "threshold exit; host depth images in, 4x4 + trace out")
+    return res
 
 
 # --------------------------------------------------------------------------------- N > 1 --
