@@ -595,19 +595,23 @@ def bench_frame_batch(args, torch, dist, rank, world, dev, cdev, gpu_index, rehe
     consistent = bool(torch.equal(lo, hi)) and rc == 0 and bool((Sg[:, 0] == args.iters).all()) and bool((Sg[:, 1] == 0).all())
     # key-frame broadcast (north_star: RCCL broadcast of the target cloud over xGMI), untimed
     # part of the run: rank 0's first target becomes every rank's target; median of 5
-    bcast_ms = None
+    bcast_ms = bcast_err = None
+    nt0 = 0
     if isinstance(comm, batch.RcclComm):
-        t_h = keep[0][1].cpu().numpy() if count else np.zeros((3, 1), np.float32)
-        if rank == 0:
-            ctx.set_target(t_h)
-        ts = []
-        for _ in range(5):
-            sync_all()
-            tb = time.perf_counter()
-            comm.broadcast_target(0)
-            ts.append((time.perf_counter() - tb) * 1e3)
-        bcast_ms = statistics.median(ts)
-        nt0 = ctx.target_size
+        try:  # auxiliary: never let it cost the line
+            t_h = keep[0][1].cpu().numpy() if count else np.zeros((3, 1), np.float32)
+            if rank == 0:
+                ctx.set_target(t_h)
+            ts = []
+            for _ in range(5):
+                sync_all()
+                tb = time.perf_counter()
+                comm.broadcast_target(0)
+                ts.append((time.perf_counter() - tb) * 1e3)
+            bcast_ms = statistics.median(ts)
+            nt0 = ctx.target_size
+        except Exception as e:  # noqa: BLE001
+            bcast_err = repr(e)
     if rank == 0:
         total_iters = float(Sg[:, 0].sum()) * args.steps
         out = {
@@ -622,7 +626,7 @@ def bench_frame_batch(args, torch, dist, rank, world, dev, cdev, gpu_index, rehe
                                       f"of the results per step"},
             "collectives": comm.kind, "collectives_fallback_reason": comm_err,
             "results_consistent_on_all_ranks": consistent,
-            "keyframe_broadcast_ms": bcast_ms,
+            "keyframe_broadcast_ms": bcast_ms, "keyframe_broadcast_error": bcast_err,
             "keyframe_broadcast_bytes": (3 * 4 * nt0) if bcast_ms is not None else None,
             "note": "N = 1 of this bench reports the single-pair configs[1] rate as `value` and this same 64-pair batch on "
                     "one GPU as `frame_batch.value`: scale the N > 1 lines against the latter",
