@@ -77,7 +77,25 @@ int upload_cloud(icpk_ctx* ctx, Cloud& c, const float* x, const float* y, const 
   if (n < 0 || (n > 0 && (!x || !y || !z))) return fail(ctx, ICPK_E_ARG, "bad cloud pointers/size");
   int rc = ensure_cloud(ctx, c, n);
   if (rc) return rc;
-  if (n > 0) {
+  if (n > 0 && kind == hipMemcpyHostToDevice && !sync) {
+    // frame-batch slots: pageable host memory crosses PCIe through a staging copy inside the
+    // runtime, one plane after the other and synchronously; copying into the slot's own pinned
+    // buffer here (the set-up threads do it in parallel) leaves ONE truly asynchronous DMA per cloud
+    float*& stage = (&c == &ctx->tgt) ? ctx->stage_t : ctx->stage_s;
+    int& cap = (&c == &ctx->tgt) ? ctx->stage_t_cap : ctx->stage_s_cap;
+    if (c.cap > cap) {
+      if (stage) ICPK_HIP(ctx, hipHostFree(stage));
+      stage = nullptr;
+      cap = 0;
+      ICPK_HIP(ctx, hipHostMalloc((void**)&stage, (size_t)3 * c.cap * sizeof(float), hipHostMallocDefault));
+      cap = c.cap;
+    }
+    std::memcpy(stage, x, (size_t)n * sizeof(float));
+    std::memcpy(stage + c.cap, y, (size_t)n * sizeof(float));
+    std::memcpy(stage + 2 * (size_t)c.cap, z, (size_t)n * sizeof(float));
+    // (the planes sit at the device cloud's own stride: one contiguous copy; the tails are padded below)
+    ICPK_HIP(ctx, hipMemcpyAsync(c.base, stage, ((size_t)2 * c.cap + n) * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+  } else if (n > 0) {
     ICPK_HIP(ctx, hipMemcpyAsync(c.x(), x, (size_t)n * sizeof(float), kind, ctx->stream));
     ICPK_HIP(ctx, hipMemcpyAsync(c.y(), y, (size_t)n * sizeof(float), kind, ctx->stream));
     ICPK_HIP(ctx, hipMemcpyAsync(c.z(), z, (size_t)n * sizeof(float), kind, ctx->stream));
@@ -690,6 +708,8 @@ void icpk_destroy(icpk_ctx* ctx) {
   for (void* p : dev)
     if (p) (void)hipFree(p);
   if (ctx->red_host) (void)hipHostFree(ctx->red_host);
+  if (ctx->stage_t) (void)hipHostFree(ctx->stage_t);
+  if (ctx->stage_s) (void)hipHostFree(ctx->stage_s);
   if (ctx->bp_n_host) (void)hipHostFree(ctx->bp_n_host);
   if (ctx->st_host) (void)hipHostFree(ctx->st_host);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -1551,7 +1571,9 @@ int align_batch_impl(icpk_ctx* ctx, int32_t n_pairs, const icpk_pair* pairs, con
       if (r != ICPK_OK) device_loop_disarm(sl);
       g.rc[k] = r;
     };
-    const int nthreads = g.count < ctx->batch_threads ? g.count : ctx->batch_threads;
+    // (host buffers: one thread -- concurrent host-to-device copies from several threads stall for
+    // ~9 ms at random on this runtime, tools/one_align.py --batch under ICPK_BATCH_TRACE)
+    const int nthreads = kind == hipMemcpyHostToDevice ? 1 : (g.count < ctx->batch_threads ? g.count : ctx->batch_threads);
     if (nthreads <= 1) {
       for (int k = 0; k < g.count; ++k) setup_one(k);
     } else {

@@ -73,6 +73,9 @@ struct icpk_ctx {
   LoopState* st_host = nullptr;  // pinned staging copy
   const int* stop = nullptr;     // &st_dev->done while a device loop is being enqueued, else null
   LoopState* st_active = nullptr;  // st_dev while a device loop is being enqueued, else null
+  float* stage_t = nullptr;  // pinned staging of host clouds (frame-batch slots): target, source
+  float* stage_s = nullptr;
+  int stage_t_cap = 0, stage_s_cap = 0;
   uint16_t* depth_dev = nullptr;
   uint16_t* depth_flt = nullptr;  // filtered depth image (icpk_filter_depth_image / icpk_backproject_filtered)
   int32_t* ks_buf = nullptr;      // key-point association lists: assoc_q | assoc_t | assoc_d | rej_q, ks_cap entries each
