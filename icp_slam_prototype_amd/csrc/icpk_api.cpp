@@ -1359,9 +1359,37 @@ int ensure_slots(icpk_ctx* ctx, int n) {
 }
 
 // uploads + everything up to (not including) the first host wait of the pair's set-up
+// device-resident pair into a slot: one launch per cloud (planes, padding and, for the source,
+// the working copy) instead of the seven copies and six fills of the general upload path
+int slot_ingest_device(icpk_ctx* sl, const icpk_pair& pr) {
+  if (pr.nt < 0 || pr.ns < 0 || (pr.nt > 0 && (!pr.tx || !pr.ty || !pr.tz)) || (pr.ns > 0 && (!pr.sx || !pr.sy || !pr.sz)))
+    return fail(sl, ICPK_E_ARG, "bad cloud pointers/size");
+  ICPK_HIP(sl, hipSetDevice(sl->device));
+  int rc = ensure_cloud(sl, sl->tgt, pr.nt);
+  if (rc == ICPK_OK) rc = ensure_cloud(sl, sl->src0, pr.ns);
+  if (rc == ICPK_OK) rc = ensure_cloud(sl, sl->src, pr.ns);
+  if (rc) return rc;
+  launch_ingest_cloud(pr.tx, pr.ty, pr.tz, pr.nt, sl->tgt.cap, __builtin_inff(), sl->tgt.base, sl->tgt.cap, nullptr, 0,
+                      sl->stream);
+  // (src.cap <= src0.cap always; both paddings reach their own capacity's first NN_TILE multiple above n)
+  const int spad = round_up(pr.ns < 1 ? 1 : pr.ns, NN_TILE);
+  launch_ingest_cloud(pr.sx, pr.sy, pr.sz, pr.ns, spad, 0.f, sl->src0.base, sl->src0.cap, sl->src.base, sl->src.cap,
+                      sl->stream);
+  ICPK_HIP(sl, hipGetLastError());
+  sl->have_tgt = sl->have_src = true;
+  sl->have_assoc = sl->have_dec = sl->have_boxes = sl->have_grid = sl->have_seed = sl->have_normals = false;
+  sl->have_qperm = false;
+  return ICPK_OK;
+}
+
 int slot_setup_phase1(icpk_ctx* sl, const icpk_pair& pr, hipMemcpyKind kind) {
-  int rc = set_target_impl(sl, pr.tx, pr.ty, pr.tz, pr.nt, kind, false);
-  if (rc == ICPK_OK) rc = set_source_impl(sl, pr.sx, pr.sy, pr.sz, pr.ns, kind, false);
+  int rc;
+  if (kind == hipMemcpyDeviceToDevice) {
+    rc = slot_ingest_device(sl, pr);
+  } else {
+    rc = set_target_impl(sl, pr.tx, pr.ty, pr.tz, pr.nt, kind, false);
+    if (rc == ICPK_OK) rc = set_source_impl(sl, pr.sx, pr.sy, pr.sz, pr.ns, kind, false);
+  }
   if (rc) return rc;
   rc = check_ready(sl);
   if (rc) return rc;

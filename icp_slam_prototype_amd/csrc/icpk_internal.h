@@ -236,6 +236,8 @@ void launch_p2l_reduce(const nn_key_t* best, const float* ax, const float* ay, c
 // kernels_transform.hip
 void launch_transform(float* x, float* y, float* z, int n, const Rt& rt, hipStream_t s);
 void launch_fill_f32(float* p, int n, float v, hipStream_t s);
+void launch_ingest_cloud(const float* x, const float* y, const float* z, int n, int n_pad, float pad, float* d1, int cap1,
+                         float* d2, int cap2, hipStream_t s);
 
 // kernels_backproject.hip
 // counts: [ceil(npix/1024)+1] ints scratch.  Returns nothing; *n_out (device)

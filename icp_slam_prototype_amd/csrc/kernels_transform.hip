@@ -55,4 +55,35 @@ void launch_fill_f32(float* p, int n, float v, hipStream_t s) {
   hipLaunchKernelGGL(fill_f32_kernel, dim3(blocks), dim3(256), 0, s, p, n, v);
 }
 
+// Ingest of a device-resident cloud into a context (frame-batch set-up): the three planes, which
+// may lie anywhere, into the context's plane layout, padded up to n_pad with `pad`, and, for a source
+// cloud, into the working copy as well -- ONE launch instead of three copies, three fills and the
+// copy of the working source.  d2 == nullptr: one destination.
+__global__ __launch_bounds__(256) void ingest_cloud_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                           const float* __restrict__ z, int n, int n_pad, float pad,
+                                                           float* __restrict__ d1, int cap1, float* __restrict__ d2,
+                                                           int cap2) {
+  const int stride = gridDim.x * blockDim.x;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_pad; i += stride) {
+    const bool in = i < n;
+    const float vx = in ? x[i] : pad, vy = in ? y[i] : pad, vz = in ? z[i] : pad;
+    d1[i] = vx;
+    d1[(size_t)cap1 + i] = vy;
+    d1[2 * (size_t)cap1 + i] = vz;
+    if (d2) {
+      d2[i] = vx;
+      d2[(size_t)cap2 + i] = vy;
+      d2[2 * (size_t)cap2 + i] = vz;
+    }
+  }
+}
+
+void launch_ingest_cloud(const float* x, const float* y, const float* z, int n, int n_pad, float pad, float* d1, int cap1,
+                         float* d2, int cap2, hipStream_t s) {
+  if (n_pad <= 0) return;
+  int blocks = (n_pad + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(ingest_cloud_kernel, dim3(blocks), dim3(256), 0, s, x, y, z, n, n_pad, pad, d1, cap1, d2, cap2);
+}
+
 }  // namespace icpk
