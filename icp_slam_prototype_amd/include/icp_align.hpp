@@ -243,6 +243,7 @@ inline void toEulerianAngle(const float rotation[9], float& x, float& y, float& 
 class Tracker {
  public:
   explicit Tracker(Engine& eng, float fx = ICPK_FX, float cx = ICPK_CX) : eng_(eng), fx_(fx), cx_(cx) { reset(); }
+  Engine& engine() const { return eng_; }
 
   void reset() {
     static const float I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};

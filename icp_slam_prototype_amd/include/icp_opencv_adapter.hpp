@@ -42,6 +42,16 @@ inline cv::Mat getTransformation(cv::Mat& data, cv::Mat& previous, cv::Mat /*col
   return rigidTransformation;
 }
 
+// SLAM.cpp:553-574 (SLAM.hpp:34): same signature as the reference's global filterDepthImage, in
+// place on the CV_16UC1 image; the colour image is not touched (the reference does not touch it either)
+inline void filterDepthImage(cv::Mat& image, cv::Mat& /*rgbImage*/, int maxDistance, int minDistance) {
+  CV_Assert(image.type() == CV_16UC1);
+  cv::Mat d = image.isContinuous() ? image : image.clone();
+  const int rc = filterDepthImage(default_tracker().engine(), d.ptr<uint16_t>(), d.rows, d.cols, maxDistance, minDistance);
+  CV_Assert(rc == ICPK_OK);
+  if (d.data != image.data) d.copyTo(image);
+}
+
 inline cv::Mat makeRotationMatrix(float x, float y, float z) {  // icp.cpp:640-653
   cv::Mat m(3, 3, CV_32FC1);
   icpk_make_rotation_matrix(x, y, z, m.ptr<float>());
