@@ -754,10 +754,9 @@ static int set_source_impl(icpk_ctx* ctx, const float* x, const float* y, const 
   ctx->have_assoc = false;
   ctx->have_seed = false;
   ctx->have_qperm = false;
-  rc = copy_src0_to_src(ctx);
-  if (rc) return rc;
-  if (sync) ICPK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  return ICPK_OK;
+  // (no second wait: the host buffers have been consumed by upload_cloud; the device-side copy of the
+  // working source is stream-ordered before anything that uses it)
+  return copy_src0_to_src(ctx);
 }
 
 int icpk_set_target(icpk_ctx* ctx, const float* x, const float* y, const float* z, int32_t n) {
@@ -782,8 +781,7 @@ int icpk_reset_source(icpk_ctx* ctx) {
   ctx->have_assoc = false;
   ctx->have_seed = false;
   ctx->have_qperm = false;
-  ICPK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  return ICPK_OK;
+  return ICPK_OK;  // device-side copy, stream-ordered: no host wait
 }
 
 int icpk_commit_source(icpk_ctx* ctx) {
@@ -795,8 +793,7 @@ int icpk_commit_source(icpk_ctx* ctx) {
   ICPK_HIP(ctx, hipMemcpyAsync(b.x(), a.x(), (size_t)m * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
   ICPK_HIP(ctx, hipMemcpyAsync(b.y(), a.y(), (size_t)m * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
   ICPK_HIP(ctx, hipMemcpyAsync(b.z(), a.z(), (size_t)m * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
-  ICPK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  return ICPK_OK;
+  return ICPK_OK;  // stream-ordered: no host wait
 }
 
 int icpk_get_source(icpk_ctx* ctx, float* x, float* y, float* z) {
@@ -886,8 +883,7 @@ int icpk_transform_source(icpk_ctx* ctx, const float R[9], const float t[3]) {
   launch_transform(ctx->src.x(), ctx->src.y(), ctx->src.z(), ctx->src.n, rt, ctx->stream);
   ICPK_HIP(ctx, hipGetLastError());
   ctx->have_assoc = false;
-  ICPK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  return ICPK_OK;
+  return ICPK_OK;  // (R and t travel by value in the kernel arguments: no host wait)
 }
 
 // ---- device-side loop: begin / finish, shared by the single-pair and the frame-batch path ----
@@ -1083,8 +1079,7 @@ int icpk_transform_target(icpk_ctx* ctx, const float R[9], const float t[3]) {
   ctx->have_boxes = false;
   ctx->have_grid = false;
   ctx->have_seed = false;
-  ICPK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  return ICPK_OK;
+  return ICPK_OK;  // stream-ordered: no host wait
 }
 
 int icpk_get_trace(icpk_ctx* ctx, int32_t* n_iter, float* R_out, float* t_out, int32_t* pairs_out, float* mse_out) {
@@ -1742,8 +1737,7 @@ static int backproject_impl(icpk_ctx* ctx, const uint16_t* depth, int32_t rows, 
   } else {
     ctx->have_tgt = true;
   }
-  ICPK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  return n;
+  return n;  // (the depth image was consumed before the count came back: no second host wait)
 }
 
 int icpk_backproject_filtered(icpk_ctx* ctx, const uint16_t* depth, int32_t rows, int32_t cols, float fx, float cx,
