@@ -63,6 +63,22 @@ def build_cpp_test(force=False):
     return CPP_TEST
 
 
+FAKE_RCCL = os.path.join(LIBDIR, "libfake_rccl.so")
+
+
+def build_fake_rccl(force=False):
+    """TEST INFRASTRUCTURE: tests/cpp/fake_rccl.cpp (collectives over shared memory for ranks that share
+    one GPU), loaded through ICPK_RCCL_LIB by tests/test_gpu_comm_two_ranks.py only."""
+    src = os.path.join(ROOT, "tests", "cpp", "fake_rccl.cpp")
+    os.makedirs(LIBDIR, exist_ok=True)
+    if not force and os.path.exists(FAKE_RCCL) and os.path.getmtime(FAKE_RCCL) >= os.path.getmtime(src):
+        return FAKE_RCCL
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    subprocess.check_call([hipcc, "-O2", "-std=c++17", "-fPIC", "-shared", "-x", "hip", "--offload-arch=gfx950", src, "-o",
+                           FAKE_RCCL, "-lrt"])
+    return FAKE_RCCL
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
     print(build_cpp_test(force="--force" in sys.argv))

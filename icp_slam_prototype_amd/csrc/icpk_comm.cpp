@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>  // types and enums only
 
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -45,9 +46,16 @@ RcclApi* rccl() {
   static RcclApi api;
   static std::once_flag once;
   std::call_once(once, [] {
-    for (const char* name : {"librccl.so.1", "librccl.so"}) {
-      api.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-      if (api.handle) break;
+    // ICPK_RCCL_LIB: test hook -- tests/cpp/fake_rccl.cpp stands in for RCCL so that two ranks sharing
+    // the one GPU of the test box can exercise the world > 1 paths below (real RCCL refuses that)
+    const char* over = std::getenv("ICPK_RCCL_LIB");
+    if (over && *over) {
+      api.handle = dlopen(over, RTLD_NOW | RTLD_LOCAL);
+    } else {
+      for (const char* name : {"librccl.so.1", "librccl.so"}) {
+        api.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        if (api.handle) break;
+      }
     }
     if (!api.handle) {
       const char* e = dlerror();
