@@ -539,7 +539,8 @@ def bench_frame_batch(args, torch, dist, rank, world, dev, cdev, gpu_index, rehe
     ctx = binding.Context(gpu_index)
     comm = None
     comm_err = None
-    if args.comm in ("auto", "icpk") and not rehearsal:
+    # (rehearsal on one GPU: the C-ABI communicator only with the shared-memory stand-in of the tests)
+    if args.comm in ("auto", "icpk") and (not rehearsal or os.environ.get("ICPK_RCCL_LIB")):
         def exchange(uid):  # rank 0's 128-byte id to everybody, over the launcher's process group
             box = [uid]
             dist.broadcast_object_list(box, src=0)

@@ -15,12 +15,12 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_two_rank_frame_batch_line():
+def _run(extra_env):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    env = dict(os.environ, ICPK_BENCH_REHEARSAL="1", MASTER_ADDR="127.0.0.1")
+    env = dict(os.environ, ICPK_BENCH_REHEARSAL="1", MASTER_ADDR="127.0.0.1", **extra_env)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
            "--batch-pairs", "6"]
@@ -33,4 +33,21 @@ def test_two_rank_frame_batch_line():
     assert d["scaling"] == "strong" and d["higher_is_better"] is True and d["vs_baseline"] is None
     assert d["config"]["frame_pairs_per_step"] == 6 and d["config"]["pairs_per_gpu"] == 3
     assert d["results_consistent_on_all_ranks"] is True
+    return d
+
+
+def test_two_rank_frame_batch_line():
+    d = _run({})
     assert d["collectives"].startswith("torch.distributed(gloo")
+
+
+def test_two_rank_frame_batch_line_through_the_c_abi_communicator():
+    """the path the driver's multi-GPU run takes -- RcclComm: id exchange over the launcher's process group,
+    icpk_comm_init_rccl, icpk_comm_gather_results every step, the key-frame broadcast -- with the
+    shared-memory stand-in for the collectives (tests/cpp/fake_rccl.cpp), two ranks on one GPU"""
+    from icp_slam_prototype_amd import build
+
+    d = _run({"ICPK_RCCL_LIB": build.build_fake_rccl()})
+    assert d["collectives"].startswith("icpk_comm") and d["collectives_fallback_reason"] is None
+    assert d["keyframe_broadcast_ms"] is not None and d["keyframe_broadcast_error"] is None
+    assert d["keyframe_broadcast_bytes"] > 0
