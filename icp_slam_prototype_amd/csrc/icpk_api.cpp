@@ -628,6 +628,8 @@ static icpk_ctx* make_context(int device_id, const icpk_ctx* parent) {
   ok = ok && hipHostMalloc((void**)&ctx->bp_n_host, sizeof(int), hipHostMallocDefault) == hipSuccess;
   ok = ok && hipMalloc((void**)&ctx->st_dev, sizeof(LoopState)) == hipSuccess;
   ok = ok && hipHostMalloc((void**)&ctx->st_host, sizeof(LoopState), hipHostMallocDefault) == hipSuccess;
+  ok = ok && hipHostMalloc((void**)&ctx->progress, 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess;
+  ok = ok && hipHostGetDevicePointer((void**)&ctx->progress_dev, ctx->progress, 0) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&ctx->ready_ev, hipEventDisableTiming) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&ctx->group_ev[0], hipEventDisableTiming) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&ctx->group_ev[1], hipEventDisableTiming) == hipSuccess;
@@ -688,6 +690,10 @@ int icpk_create(icpk_ctx** out, int device_id) {
     const int v = std::atoi(e);
     if (v >= 1 && v <= 16) ctx->batch_threads = v;
   }
+  if (const char* e = std::getenv("ICPK_LOOP_AHEAD")) {  // 0: enqueue every iteration up front
+    const int v = std::atoi(e);
+    if (v >= 0 && v <= LOOP_MAX_ITER) ctx->loop_ahead = v;
+  }
   *out = ctx;
   return ICPK_OK;
 }
@@ -712,6 +718,7 @@ void icpk_destroy(icpk_ctx* ctx) {
   if (ctx->stage_s) (void)hipHostFree(ctx->stage_s);
   if (ctx->bp_n_host) (void)hipHostFree(ctx->bp_n_host);
   if (ctx->st_host) (void)hipHostFree(ctx->st_host);
+  if (ctx->progress) (void)hipHostFree(ctx->progress);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -893,9 +900,13 @@ static int loop_nsum(const icpk_params* p) {
 }
 
 // initial LoopState -> device (on ctx->stream), stop flags armed
-static int device_loop_begin(icpk_ctx* ctx, const icpk_params* p) {
+static int device_loop_begin(icpk_ctx* ctx, const icpk_params* p, bool throttled = false) {
   LoopState* h = ctx->st_host;
   std::memset(h, 0, offsetof(LoopState, trace_R));
+  if (throttled) {
+    ctx->progress[0] = ctx->progress[1] = 0;
+    h->progress = ctx->progress_dev;
+  }
   h->Trot[0] = h->Trot[4] = h->Trot[8] = 1.f;
   h->Tk[0] = h->Tk[5] = h->Tk[10] = 1.0;
   h->max_iterations = p->max_iterations;
@@ -962,8 +973,40 @@ static int device_loop_finish(icpk_ctx* ctx, const icpk_params* p, float T_out[1
   return h->status;
 }
 
-// Whole alignment enqueued up front; loop test, solve and pose accumulation run on the
-// device (kernels_loop.hip).  Same results as the host loop below.
+// host side of LoopState::progress: returns once `steps` loop steps have run on the device or the loop has
+// exited.  Spins (the wait is a fraction of one iteration), yields when a sweep is long, and looks at the
+// stream now and then so that a faulted kernel ends the wait with an error instead of hanging the caller.
+static int wait_loop_progress(icpk_ctx* ctx, int steps, bool* exited) {
+  volatile int* pr = ctx->progress;
+  auto t_query = std::chrono::steady_clock::now() + std::chrono::milliseconds(20);
+  for (unsigned spin = 1;; ++spin) {
+    const int k = __atomic_load_n(&pr[0], __ATOMIC_ACQUIRE);
+    if (pr[1]) {
+      *exited = true;
+      return ICPK_OK;
+    }
+    if (k >= steps) return ICPK_OK;
+    __builtin_ia32_pause();
+    if ((spin & 0x3ff) != 0) continue;
+    std::this_thread::yield();
+    const auto now = std::chrono::steady_clock::now();
+    if (now < t_query) continue;
+    // (not more often: a stream query may itself put a marker into the queue)
+    t_query = now + std::chrono::milliseconds(20);
+    const hipError_t q = hipStreamQuery(ctx->stream);
+    if (q == hipSuccess) {  // drained: the words are final
+      *exited = pr[1] != 0;
+      if (!*exited && __atomic_load_n(&pr[0], __ATOMIC_ACQUIRE) < steps)
+        return fail(ctx, ICPK_E_HIP, "device loop made no progress");
+      return ICPK_OK;
+    }
+    if (q != hipErrorNotReady) return fail(ctx, ICPK_E_HIP, hipGetErrorString(q));
+  }
+}
+
+// Whole alignment enqueued up front (or, when the loop may leave early, a few iterations ahead of the
+// device); loop test, solve and pose accumulation run on the device (kernels_loop.hip).  Same results
+// as the host loop below.
 static int align_device_loop(icpk_ctx* ctx, const icpk_params* p, float T_out[16], icpk_stats* stats) {
   const bool prof = p->profile != 0;
   const bool prof_all = p->profile >= 2;  // 1: NN kernels only (2 events per sweep); 2: every stage
@@ -986,7 +1029,10 @@ static int align_device_loop(icpk_ctx* ctx, const icpk_params* p, float T_out[16
     icpk_ctx* c;
     ~Guard() { device_loop_disarm(c); }
   } guard{ctx};
-  int rc = device_loop_begin(ctx, p);
+  // a loop that may leave early is enqueued loop_ahead iterations ahead of the device, not all at once
+  const int ahead = ctx->loop_ahead;
+  const bool throttled = !p->fixed_iterations && !prof && ahead > 0 && p->max_iterations > ahead;
+  int rc = device_loop_begin(ctx, p, throttled);
   if (rc) return rc;
 
   int nsweep = 0;
@@ -1016,6 +1062,12 @@ static int align_device_loop(icpk_ctx* ctx, const icpk_params* p, float T_out[16
   rc = sweep();  // icp.cpp:98
   if (rc) return rc;
   for (int i = 0; i < p->max_iterations; ++i) {
+    if (throttled && i >= ahead) {
+      bool exited = false;
+      rc = wait_loop_progress(ctx, i - ahead + 1, &exited);
+      if (rc) return rc;
+      if (exited) break;  // everything from here on would find `done` set and do nothing
+    }
     launch_loop_step(ctx->partial, ctx->pcount, B, nsum, ctx->st_dev, 0, ctx->stream);
     if (!fused) {  // the pruned sweep applies the transform itself (K3 fused into K1c)
       if (prof_all) {

@@ -71,6 +71,9 @@ struct icpk_ctx {
   double* red_host = nullptr;  // pinned, 20 x 8 bytes
   LoopState* st_dev = nullptr;   // device-side loop state
   LoopState* st_host = nullptr;  // pinned staging copy
+  int* progress = nullptr;       // pinned, mapped: LoopState::progress of a throttled loop (see there)
+  int* progress_dev = nullptr;   // the same words as the device addresses them
+  int loop_ahead = 2;            // iterations kept enqueued ahead of the device in a loop that may exit early
   const int* stop = nullptr;     // &st_dev->done while a device loop is being enqueued, else null
   LoopState* st_active = nullptr;  // st_dev while a device loop is being enqueued, else null
   float* stage_t = nullptr;  // pinned staging of host clouds (frame-batch slots): target, source

@@ -90,6 +90,19 @@ __device__ void compose_rt(const float Rf[9], const float tf[3], double Tk[12]) 
   for (int k = 0; k < 12; ++k) Tk[k] = Tn[k];
 }
 
+// thread 0, on every way out of a loop step: tell the host (see LoopState::progress).  The words are hints
+// that only decide how much the host enqueues -- a stale read costs a no-op launch, never a result -- so
+// the stores are relaxed: no release, which at system scope would write the whole L2 back.
+__device__ __forceinline__ void publish_progress(LoopState* __restrict__ st) {
+  const int k = st->steps + 1;
+  st->steps = k;
+  int* pr = st->progress;
+  if (pr) {
+    __hip_atomic_store(pr + 1, st->done | st->stop_after_transform, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(pr, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
 template <int NS, int NACT = NS>
 __device__ __forceinline__ void loop_step_body(const double* __restrict__ partial, const int* __restrict__ pcount,
                                                int nblocks, LoopState* __restrict__ st, int stats_only) {
@@ -103,9 +116,15 @@ __device__ __forceinline__ void loop_step_body(const double* __restrict__ partia
   long long npairs = 0;
   tree_stage2<NS, NACT>(partial, pcount, nblocks, sums, npairs);  // sums [NACT..NS) read as 0
   STEP_STAMP(i, 1);
-  if (done) return;
+  if (done) {
+    if (threadIdx.x == 0) publish_progress(st);
+    return;
+  }
   if (stop_after) {  // the fallback motion has been applied by the previous transform
-    if (threadIdx.x == 0) st->done = 1;
+    if (threadIdx.x == 0) {
+      st->done = 1;
+      publish_progress(st);
+    }
     return;
   }
   if (threadIdx.x != 0) return;
@@ -122,6 +141,7 @@ __device__ __forceinline__ void loop_step_body(const double* __restrict__ partia
 
   if (!((fixed || mse > threshold) && i < max_iterations)) {  // icp.cpp:155
     st->done = 1;
+    publish_progress(st);
     return;
   }
   if (npairs < min_pairs) {  // icp.cpp:163-182
@@ -132,6 +152,7 @@ __device__ __forceinline__ void loop_step_body(const double* __restrict__ partia
     }
     st->status = 1;  // ICPK_W_TOO_FEW_PAIRS
     st->stop_after_transform = 1;
+    publish_progress(st);
     return;
   }
   st->trace_pairs[i] = (int)npairs;
@@ -143,6 +164,7 @@ __device__ __forceinline__ void loop_step_body(const double* __restrict__ partia
     if (!solve_p2l(sums, Rd, td)) {
       st->status = 2;  // ICPK_W_DEGENERATE
       st->done = 1;
+      publish_progress(st);
       return;
     }
     for (int k = 0; k < 9; ++k) Rrec[k] = (float)Rd[k];
@@ -189,6 +211,7 @@ __device__ __forceinline__ void loop_step_body(const double* __restrict__ partia
   for (int k = 0; k < 9; ++k) st->trace_R[9 * i + k] = Rrec[k];
   for (int k = 0; k < 3; ++k) st->trace_t[3 * i + k] = trec[k];
   st->iterations = i + 1;  // icp.cpp:257 (the sweep that follows is already enqueued)
+  publish_progress(st);
   STEP_STAMP(i, 4);
 }
 

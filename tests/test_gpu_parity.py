@@ -694,6 +694,38 @@ def test_device_loop_equals_host_loop(ctx, oracle, solve, mode):
     assert out[1][1] < 16  # the threshold run really exits early
 
 
+def test_throttled_loop_equals_loop_enqueued_up_front(monkeypatch):
+    """A loop that may exit early is enqueued ICPK_LOOP_AHEAD iterations ahead of the device (LoopState::
+    progress) instead of all at once: same bits for every look-ahead and every exit iteration, the too-few-
+    pairs fallback included."""
+    p = synth.frustum_pair(3000, seed=21, rot_deg=(0.4, 0.8, -0.3), shift=(0.01, -0.004, 0.006))
+    far = p["source"] + np.float32(100)
+    runs = {}
+    for ahead in (0, 1, 2, 3, 6):
+        monkeypatch.setenv("ICPK_LOOP_AHEAD", str(ahead))
+        with binding.Context(0) as c:
+            c.set_target(p["target"])
+            c.set_source(p["source"])
+            c.align(max_iterations=12, fixed_iterations=1, solve=binding.SOLVE_KABSCH)
+            mses = [float(t["mse"]) for t in c.get_trace()]
+            out = []
+            for k in (0, 1, 4, 9, 11):  # exit when entering iteration k (and never: threshold 0)
+                for thr in (mses[k], 0.0):
+                    c.reset_source()
+                    T, st, rc = c.align(max_iterations=12, threshold=thr, solve=binding.SOLVE_KABSCH)
+                    idx, dist = c.get_associations()
+                    out.append((rc, st.iterations, st.status, st.final_pairs, st.final_mse, st.nn_launches, T.tobytes(),
+                                idx.tobytes(), dist.tobytes(), c.get_source().tobytes(), len(c.get_trace())))
+            c.set_source(far)  # nothing within range: icp.cpp:163-182, then stop
+            T, st, rc = c.align(max_iterations=12, threshold=1e-9, max_nn_dist=0.5, last_translation=[1, 2, 3])
+            out.append((rc, st.iterations, st.status, st.final_pairs, T.tobytes(), c.get_source().tobytes()))
+        runs[ahead] = out
+    its = [o[1] for o in runs[0][:-1]]
+    assert min(its) <= 1 and max(its) == 12 and len(set(its)) >= 4, its
+    for ahead, out in runs.items():
+        assert out == runs[0], ahead
+
+
 def test_device_loop_fallback_and_degenerate(ctx, oracle):
     p = synth.frustum_pair(800, seed=5, rot_deg=(0, 0.5, 0), shift=(0.002, 0, 0))
     far = p["source"] + np.float32(100)
