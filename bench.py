@@ -482,9 +482,9 @@ def extra_workload(args, torch, dev, gpu_index, name, iters, steps):
 
 def tracker_path(gpu_index):
     """The callers either side of the loop as SLAM.cpp drives them --
-    icp::Tracker::getTransformation's call sequence through the C ABI: per frame pair two 640x480
-    uint16 depth images cross PCIe, are back-projected on the device (with and without
-    filterDepthImage), posed, aligned with the reference's own settings (16 iterations at most,
+    icp::Tracker::getTransformation's call sequence through the C ABI (icpk_backproject_pair,
+    icpk_align, icpk_get_trace): per frame pair two 640x480 uint16 depth images cross PCIe, are
+    back-projected on the device (with and without filterDepthImage), posed, aligned with the reference's own settings (16 iterations at most,
     threshold 1e-4, SLAM.cpp:277) and the per-iteration trace is read back.  PCIe-inclusive by
     nature; frame pairs per second."""
     from icp_slam_prototype_amd import binding, synth
@@ -501,11 +501,7 @@ def tracker_path(gpu_index):
     res = {}
     for filt in (False, True):
         def pair(prev, cur):
-            for d, w in ((prev, 1), (cur, 0)):
-                ctx.backproject_filtered(d, which=w) if filt else ctx.backproject(d, which=w)
-            ctx.transform_target(camR, camP)
-            ctx.transform_source(camR, camP)
-            ctx.commit_source()
+            ctx.backproject_pair(cur, prev, R=camR, t=camP, filter=filt)  # icp.cpp:38-71 in one call
             T, st, rc = ctx.align(max_iterations=16, threshold=1e-4)
             ctx.get_trace(16)
             return st

@@ -35,7 +35,7 @@ SYMBOLS = [
     "icpk_align_batch", "icpk_align_batch_device", "icpk_backproject", "icpk_backproject_with_normals", "icpk_set_target_normals",
     "icpk_get_target_normals", "icpk_reduce_p2l", "icpk_solve_point_to_plane", "icpk_pair_distance", "icpk_pair_distance3", "icpk_distance3", "icpk_make_rotation_matrix",
     "icpk_matrix_to_quaternion", "icpk_quaternion_to_euler", "icpk_solve_reference", "icpk_solve_kabsch",
-    "icpk_associate_keypoints", "icpk_filter_depth_image", "icpk_backproject_filtered",
+    "icpk_associate_keypoints", "icpk_filter_depth_image", "icpk_backproject_filtered", "icpk_backproject_pair",
     "icpk_comm_unique_id", "icpk_comm_init_rccl", "icpk_comm_destroy", "icpk_comm_rank", "icpk_comm_world",
     "icpk_comm_partition", "icpk_comm_broadcast_target", "icpk_comm_gather_results", "icpk_comm_allreduce_sums",
     "icpk_comm_barrier",
@@ -164,6 +164,8 @@ def load():
     lib.icpk_filter_depth_image.argtypes = [C.c_void_p, u16, u16, C.c_int32, C.c_int32] + [C.c_int32] * 5
     lib.icpk_backproject_filtered.argtypes = [C.c_void_p, u16, C.c_int32, C.c_int32, C.c_float, C.c_float, fp,
                                               C.c_int32, C.c_int32] + [C.c_int32] * 5
+    lib.icpk_backproject_pair.argtypes = [C.c_void_p, u16, u16, C.c_int32, C.c_int32, C.c_float, C.c_float, fp, fp, fp] + \
+        [C.c_int32] * 6 + [C.POINTER(C.c_int32)] * 2
     lib.icpk_comm_unique_id.argtypes = [C.c_void_p]
     lib.icpk_comm_init_rccl.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
     lib.icpk_comm_destroy.argtypes = [C.c_void_p]
@@ -431,6 +433,26 @@ class Context:
         return self._chk(self._lib.icpk_backproject_filtered(
             self._h, depth.ctypes.data_as(C.POINTER(C.c_uint16)), rows, cols, fx, cx, None if off is None else _fp(off),
             which, normals_mode, int(max_d), int(min_d), int(bool(morph)), int(anchor[0]), int(anchor[1])))
+
+    def backproject_pair(self, depth_source, depth_target, R=None, t=None, fx=468.60, cx=318.27, offset=None, filter=False,
+                         max_d=25000, min_d=1000, morph=True, anchor=(-1, -1)):
+        """icp.cpp:38-71 in one call: both frames back-projected (filtered first if filter), posed by (R, t),
+        the posed source committed.  Returns (n_source, n_target)."""
+        ds = np.ascontiguousarray(depth_source, np.uint16)
+        dt = np.ascontiguousarray(depth_target, np.uint16)
+        if ds.shape != dt.shape or ds.ndim != 2:
+            raise ValueError("two depth images of the same rows x cols shape expected")
+        rows, cols = ds.shape
+        off = None if offset is None else _f(offset)
+        Rm = None if R is None else _f(R)
+        tv = None if t is None else _f(t)
+        ns, nt = C.c_int32(-1), C.c_int32(-1)
+        u16 = C.POINTER(C.c_uint16)
+        self._chk(self._lib.icpk_backproject_pair(
+            self._h, ds.ctypes.data_as(u16), dt.ctypes.data_as(u16), rows, cols, fx, cx, None if off is None else _fp(off),
+            None if Rm is None else _fp(Rm), None if tv is None else _fp(tv), int(bool(filter)), int(max_d), int(min_d),
+            int(bool(morph)), int(anchor[0]), int(anchor[1]), C.byref(ns), C.byref(nt)))
+        return ns.value, nt.value
 
     def associate_keypoints(self, max_dist=MAX_NN_KEYPOINT_DISTANCE, nn_mode=NN_GRID, rejected=None, capacity=None):
         """icp.cpp:488-515 on the context's clouds.  rejected: the caller's running list of rejected

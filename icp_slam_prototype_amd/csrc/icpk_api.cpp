@@ -625,7 +625,7 @@ static icpk_ctx* make_context(int device_id, const icpk_ctx* parent) {
   ok = ok && hipMalloc((void**)&ctx->pcount, (size_t)RED_MAX_BLOCKS * sizeof(int)) == hipSuccess;
   ok = ok && hipMalloc((void**)&ctx->red_out, (NSUM_MAX + 1) * sizeof(double)) == hipSuccess;
   ok = ok && hipHostMalloc((void**)&ctx->red_host, (NSUM_MAX + 1) * sizeof(double), hipHostMallocDefault) == hipSuccess;
-  ok = ok && hipHostMalloc((void**)&ctx->bp_n_host, sizeof(int), hipHostMallocDefault) == hipSuccess;
+  ok = ok && hipHostMalloc((void**)&ctx->bp_n_host, 2 * sizeof(int), hipHostMallocDefault) == hipSuccess;
   ok = ok && hipMalloc((void**)&ctx->st_dev, sizeof(LoopState)) == hipSuccess;
   ok = ok && hipHostMalloc((void**)&ctx->st_host, sizeof(LoopState), hipHostMallocDefault) == hipSuccess;
   ok = ok && hipHostMalloc((void**)&ctx->progress, 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess;
@@ -1715,6 +1715,27 @@ static int check_filter(icpk_ctx* ctx, int morph, int& ax, int& ay) {
   return ICPK_OK;
 }
 
+// raw + filtered depth images on the device (`count` pixels each) and `ints` block-count words
+static int ensure_depth_buffers(icpk_ctx* ctx, int count, int ints) {
+  if (count > ctx->depth_cap) {
+    if (ctx->depth_dev) ICPK_HIP(ctx, hipFree(ctx->depth_dev));
+    if (ctx->depth_flt) ICPK_HIP(ctx, hipFree(ctx->depth_flt));
+    ctx->depth_dev = ctx->depth_flt = nullptr;
+    ctx->depth_cap = 0;
+    ICPK_HIP(ctx, hipMalloc((void**)&ctx->depth_dev, (size_t)count * sizeof(uint16_t)));
+    ICPK_HIP(ctx, hipMalloc((void**)&ctx->depth_flt, (size_t)count * sizeof(uint16_t)));
+    ctx->depth_cap = count;
+  }
+  if (ints > ctx->bp_counts_cap) {
+    if (ctx->bp_counts) ICPK_HIP(ctx, hipFree(ctx->bp_counts));
+    ctx->bp_counts = nullptr;
+    ctx->bp_counts_cap = 0;
+    ICPK_HIP(ctx, hipMalloc((void**)&ctx->bp_counts, (size_t)ints * sizeof(int)));
+    ctx->bp_counts_cap = ints;
+  }
+  return ICPK_OK;
+}
+
 static int backproject_impl(icpk_ctx* ctx, const uint16_t* depth, int32_t rows, int32_t cols, float fx, float cx,
                             const float offset[3], int32_t which, int normals_mode /* <0: none */,
                             const DepthFilter* flt = nullptr) {
@@ -1723,26 +1744,11 @@ static int backproject_impl(icpk_ctx* ctx, const uint16_t* depth, int32_t rows, 
     return ICPK_E_ARG;
   ICPK_HIP(ctx, hipSetDevice(ctx->device));
   const int npix = rows * cols;
-  if (npix > ctx->depth_cap) {
-    if (ctx->depth_dev) ICPK_HIP(ctx, hipFree(ctx->depth_dev));
-    ctx->depth_dev = nullptr;
-    ctx->depth_cap = 0;
-    ICPK_HIP(ctx, hipMalloc((void**)&ctx->depth_dev, (size_t)npix * sizeof(uint16_t)));
-    if (ctx->depth_flt) ICPK_HIP(ctx, hipFree(ctx->depth_flt));
-    ctx->depth_flt = nullptr;
-    ICPK_HIP(ctx, hipMalloc((void**)&ctx->depth_flt, (size_t)npix * sizeof(uint16_t)));
-    ctx->depth_cap = npix;
-  }
   const int nblocks = (npix + 1023) / 1024;
-  if (nblocks + 1 > ctx->bp_counts_cap) {
-    if (ctx->bp_counts) ICPK_HIP(ctx, hipFree(ctx->bp_counts));
-    ctx->bp_counts = nullptr;
-    ctx->bp_counts_cap = 0;
-    ICPK_HIP(ctx, hipMalloc((void**)&ctx->bp_counts, (size_t)(nblocks + 2) * sizeof(int)));
-    ctx->bp_counts_cap = nblocks + 2;
-  }
+  int rc = ensure_depth_buffers(ctx, npix, nblocks + 2);
+  if (rc) return rc;
   Cloud& c = which == 0 ? ctx->src0 : ctx->tgt;
-  int rc = ensure_cloud(ctx, c, npix);  // worst case: every pixel valid
+  rc = ensure_cloud(ctx, c, npix);  // worst case: every pixel valid
   if (rc) return rc;
   ICPK_HIP(ctx, hipMemcpyAsync(ctx->depth_dev, depth, (size_t)npix * sizeof(uint16_t), hipMemcpyHostToDevice, ctx->stream));
   const uint16_t* dimg = ctx->depth_dev;
@@ -1792,6 +1798,61 @@ static int backproject_impl(icpk_ctx* ctx, const uint16_t* depth, int32_t rows, 
   return n;  // (the depth image was consumed before the count came back: no second host wait)
 }
 
+int icpk_backproject_pair(icpk_ctx* ctx, const uint16_t* depth_source, const uint16_t* depth_target, int32_t rows,
+                          int32_t cols, float fx, float cx, const float offset[3], const float R[9], const float t[3],
+                          int32_t filter, int32_t max_d, int32_t min_d, int32_t morph, int32_t anchor_x, int32_t anchor_y,
+                          int32_t* n_source, int32_t* n_target) {
+  if (!ctx || !depth_source || !depth_target || rows <= 0 || cols <= 0 || (int64_t)rows * cols > (1 << 27) || (!R != !t))
+    return ICPK_E_ARG;
+  int ax = anchor_x, ay = anchor_y;
+  int rc = filter ? check_filter(ctx, morph, ax, ay) : ICPK_OK;
+  if (rc) return rc;
+  ICPK_HIP(ctx, hipSetDevice(ctx->device));
+  const int npix = rows * cols;
+  const int nblocks = (npix + 1023) / 1024;
+  const int per_image = nblocks + 2;
+  rc = ensure_depth_buffers(ctx, 2 * npix, 2 * per_image + 2);
+  if (rc) return rc;
+  for (Cloud* c : {&ctx->src0, &ctx->src, &ctx->tgt}) {
+    rc = ensure_cloud(ctx, *c, npix);  // worst case: every pixel valid
+    if (rc) return rc;
+  }
+  const size_t bytes = (size_t)npix * sizeof(uint16_t);
+  ICPK_HIP(ctx, hipMemcpyAsync(ctx->depth_dev, depth_source, bytes, hipMemcpyHostToDevice, ctx->stream));
+  ICPK_HIP(ctx, hipMemcpyAsync(ctx->depth_dev + npix, depth_target, bytes, hipMemcpyHostToDevice, ctx->stream));
+  const uint16_t* img = ctx->depth_dev;
+  if (filter) {  // SLAM.cpp:229,553-574: the frames are filtered before they are back-projected
+    for (int k = 0; k < 2; ++k)
+      launch_depth_filter(ctx->depth_dev + (size_t)k * npix, ctx->depth_flt + (size_t)k * npix, rows, cols, min_d, max_d, ax,
+                          ay, morph != 0, ctx->stream);
+    img = ctx->depth_flt;
+  }
+  BpPair b;
+  b.im[0] = BpImage{img, ctx->src0.x(), ctx->src0.y(), ctx->src0.z(), ctx->src.x(), ctx->src.y(), ctx->src.z(),
+                    ctx->bp_counts, 0.f};
+  b.im[1] = BpImage{img + npix, ctx->tgt.x(), ctx->tgt.y(), ctx->tgt.z(), nullptr, nullptr, nullptr,
+                    ctx->bp_counts + per_image, __builtin_inff()};
+  Rt rt{};
+  if (R) {
+    std::memcpy(rt.R, R, sizeof(rt.R));
+    std::memcpy(rt.t, t, sizeof(rt.t));
+  }
+  int* n_dev = ctx->bp_counts + 2 * per_image;
+  launch_backproject_pair(b, rows, cols, fx, cx, offset ? offset[0] : 0.f, offset ? offset[1] : 0.f,
+                          offset ? offset[2] : 0.f, rt, R != nullptr, n_dev, ctx->stream);
+  ICPK_HIP(ctx, hipGetLastError());
+  ICPK_HIP(ctx, hipMemcpyAsync(ctx->bp_n_host, n_dev, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  ICPK_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the one host wait: both counts (and both images consumed)
+  ctx->src0.n = ctx->src.n = ctx->bp_n_host[0];
+  ctx->tgt.n = ctx->bp_n_host[1];
+  ctx->have_src = ctx->have_tgt = true;
+  ctx->have_assoc = ctx->have_seed = ctx->have_qperm = false;
+  ctx->have_dec = ctx->have_boxes = ctx->have_grid = ctx->have_normals = false;
+  if (n_source) *n_source = ctx->src.n;
+  if (n_target) *n_target = ctx->tgt.n;
+  return ICPK_OK;
+}
+
 int icpk_backproject_filtered(icpk_ctx* ctx, const uint16_t* depth, int32_t rows, int32_t cols, float fx, float cx,
                               const float offset[3], int32_t which, int32_t normals_mode, int32_t max_d,
                               int32_t min_d, int32_t morph, int32_t anchor_x, int32_t anchor_y) {
@@ -1812,15 +1873,8 @@ int icpk_filter_depth_image(icpk_ctx* ctx, const uint16_t* depth_in, uint16_t* d
   if (rc) return rc;
   ICPK_HIP(ctx, hipSetDevice(ctx->device));
   const int npix = rows * cols;
-  if (npix > ctx->depth_cap) {
-    if (ctx->depth_dev) ICPK_HIP(ctx, hipFree(ctx->depth_dev));
-    if (ctx->depth_flt) ICPK_HIP(ctx, hipFree(ctx->depth_flt));
-    ctx->depth_dev = ctx->depth_flt = nullptr;
-    ctx->depth_cap = 0;
-    ICPK_HIP(ctx, hipMalloc((void**)&ctx->depth_dev, (size_t)npix * sizeof(uint16_t)));
-    ICPK_HIP(ctx, hipMalloc((void**)&ctx->depth_flt, (size_t)npix * sizeof(uint16_t)));
-    ctx->depth_cap = npix;
-  }
+  rc = ensure_depth_buffers(ctx, npix, 0);
+  if (rc) return rc;
   ICPK_HIP(ctx, hipMemcpyAsync(ctx->depth_dev, depth_in, (size_t)npix * sizeof(uint16_t), hipMemcpyHostToDevice, ctx->stream));
   launch_depth_filter(ctx->depth_dev, ctx->depth_flt, rows, cols, min_d, max_d, ax, ay, morph != 0, ctx->stream);
   ICPK_HIP(ctx, hipGetLastError());
@@ -1855,13 +1909,8 @@ int icpk_associate_keypoints(icpk_ctx* ctx, int32_t nn_mode, float max_dist, int
     ctx->ks_cap = cap;
   }
   const int nblocks = (nq + 1023) / 1024;
-  if (nblocks + 2 > ctx->bp_counts_cap) {
-    if (ctx->bp_counts) ICPK_HIP(ctx, hipFree(ctx->bp_counts));
-    ctx->bp_counts = nullptr;
-    ctx->bp_counts_cap = 0;
-    ICPK_HIP(ctx, hipMalloc((void**)&ctx->bp_counts, (size_t)(nblocks + 2) * sizeof(int)));
-    ctx->bp_counts_cap = nblocks + 2;
-  }
+  rc = ensure_depth_buffers(ctx, 0, nblocks + 2);
+  if (rc) return rc;
   int32_t* dq = ctx->ks_buf;
   int32_t* dt = dq + ctx->ks_cap;
   float* dd = reinterpret_cast<float*>(dt + ctx->ks_cap);

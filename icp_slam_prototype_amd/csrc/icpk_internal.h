@@ -251,6 +251,20 @@ void launch_ingest_cloud(const float* x, const float* y, const float* z, int n, 
 void launch_backproject(const uint16_t* depth, int rows, int cols, float fx, float cx, float ox, float oy, float oz,
                         float* x, float* y, float* z, float* nx, float* ny, float* nz, int normals_mode,
                         int* block_counts, int* n_out, hipStream_t s);
+// icpk_backproject_pair: image 0 = current frame (source; x2/y2/z2 = its working copy), image 1 = previous
+// frame (target).  counts: nblocks + 2 ints per image.
+struct BpImage {
+  const uint16_t* depth;
+  float *x, *y, *z;
+  float *x2, *y2, *z2;
+  int* counts;
+  float pad;
+};
+struct BpPair {
+  BpImage im[2];
+};
+void launch_backproject_pair(const BpPair& b, int rows, int cols, float fx, float cx, float ox, float oy, float oz,
+                             const Rt& rt, int posed, int* n_out, hipStream_t s);
 
 // kernels_frontend.hip
 // order-preserving split of a sweep's result into accepted pairs and rejected queries

@@ -16,9 +16,9 @@ constexpr int BP_THREADS = 256;
 constexpr int BP_PER_THREAD = 4;
 constexpr int BP_BLOCK = BP_THREADS * BP_PER_THREAD;  // 1024 pixels per workgroup
 
-__global__ __launch_bounds__(BP_THREADS) void bp_count_kernel(const uint16_t* __restrict__ depth, int npix,
-                                                              int* __restrict__ block_counts) {
-  const int base = blockIdx.x * BP_BLOCK;
+__device__ __forceinline__ void bp_count_body(const uint16_t* __restrict__ depth, int npix,
+                                              int* __restrict__ block_counts, const int block) {
+  const int base = block * BP_BLOCK;
   int c = 0;
 #pragma unroll
   for (int k = 0; k < BP_PER_THREAD; ++k) {
@@ -29,11 +29,21 @@ __global__ __launch_bounds__(BP_THREADS) void bp_count_kernel(const uint16_t* __
   __shared__ int wc[BP_THREADS / 64];
   if ((threadIdx.x & 63) == 0) wc[threadIdx.x >> 6] = c;
   __syncthreads();
-  if (threadIdx.x == 0) block_counts[blockIdx.x] = wc[0] + wc[1] + wc[2] + wc[3];
+  if (threadIdx.x == 0) block_counts[block] = wc[0] + wc[1] + wc[2] + wc[3];
+}
+
+__global__ __launch_bounds__(BP_THREADS) void bp_count_kernel(const uint16_t* __restrict__ depth, int npix,
+                                                              int* __restrict__ block_counts) {
+  bp_count_body(depth, npix, block_counts, blockIdx.x);
+}
+
+// frame-pair entry (icpk_backproject_pair): blockIdx.y = image (0: current frame / source, 1: previous / target)
+__global__ __launch_bounds__(BP_THREADS) void bp_count_pair_kernel(const BpPair b, int npix) {
+  bp_count_body(b.im[blockIdx.y].depth, npix, b.im[blockIdx.y].counts, blockIdx.x);
 }
 
 // exclusive scan in place; block_counts[nblocks] receives the total
-__global__ void bp_scan_kernel(int* __restrict__ block_counts, int nblocks, int* __restrict__ n_out) {
+__device__ __forceinline__ void bp_scan_body(int* __restrict__ block_counts, int nblocks, int* __restrict__ n_out) {
   __shared__ int carry;
   __shared__ int wsum[4];
   if (threadIdx.x == 0) carry = 0;
@@ -61,6 +71,14 @@ __global__ void bp_scan_kernel(int* __restrict__ block_counts, int nblocks, int*
     block_counts[nblocks] = carry;
     *n_out = carry;
   }
+}
+
+__global__ void bp_scan_kernel(int* __restrict__ block_counts, int nblocks, int* __restrict__ n_out) {
+  bp_scan_body(block_counts, nblocks, n_out);
+}
+
+__global__ void bp_scan_pair_kernel(const BpPair b, int nblocks, int* __restrict__ n_out) {
+  bp_scan_body(b.im[blockIdx.x].counts, nblocks, n_out + blockIdx.x);
 }
 
 // Surface normal of pixel (r, c) -- point-to-plane extension (not in the reference,
@@ -152,6 +170,85 @@ __global__ __launch_bounds__(BP_THREADS) void bp_scatter_kernel(const uint16_t* 
     }
     off += wcount[k][0] + wcount[k][1] + wcount[k][2] + wcount[k][3];
   }
+}
+
+// frame-pair entry: scatter of both images with the camera pose applied on the way (icp.cpp:58-59, 70-71:
+// rotate, then translate -- the arithmetic of K3, kernels_transform.hip, on the offset point), the source
+// written to its pristine and its working copy at once, and every plane padded up to the next multiple of
+// NN_TILE (workgroup 0 of each image: the total is on the device by now).  Replaces, bit for bit,
+// icpk_backproject x 2 + icpk_transform_target / _source + icpk_commit_source: 3 launches instead of 25.
+__global__ __launch_bounds__(BP_THREADS) void bp_scatter_pair_kernel(const BpPair b, int npix, int cols, int nblocks,
+                                                                     float fx, float cx, float ox, float oy, float oz,
+                                                                     const Rt rt, int posed) {
+  const BpImage& im = b.im[blockIdx.y];
+  const uint16_t* __restrict__ depth = im.depth;
+  float* __restrict__ x = im.x;
+  float* __restrict__ y = im.y;
+  float* __restrict__ z = im.z;
+  float* __restrict__ x2 = im.x2;
+  float* __restrict__ y2 = im.y2;
+  float* __restrict__ z2 = im.z2;
+  __shared__ int wcount[BP_PER_THREAD][BP_THREADS / 64];
+  const int base = blockIdx.x * BP_BLOCK;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned long long mask[BP_PER_THREAD];
+  uint16_t dv[BP_PER_THREAD];
+#pragma unroll
+  for (int k = 0; k < BP_PER_THREAD; ++k) {
+    const int p = base + k * BP_THREADS + threadIdx.x;
+    dv[k] = p < npix ? depth[p] : (uint16_t)0;
+    mask[k] = __ballot(dv[k] != 0);
+    if (lane == 0) wcount[k][wave] = __popcll(mask[k]);
+  }
+  __syncthreads();
+  int off = im.counts[blockIdx.x];
+#pragma unroll
+  for (int k = 0; k < BP_PER_THREAD; ++k) {
+    int before = 0;
+    for (int w = 0; w < wave; ++w) before += wcount[k][w];
+    const int rank = off + before + __popcll(mask[k] & ((1ull << lane) - 1ull));
+    if (dv[k] != 0) {
+      const int p = base + k * BP_THREADS + threadIdx.x;
+      const int r = p / cols, c = p - r * cols;
+      const float pz = ((float)dv[k]) / 5000.0f;  // pointcloud.cpp:37-39
+      const float px = ((float)c - cx) * pz / fx;
+      const float py = ((float)r - cx) * pz / fx;
+      float vx = px + ox, vy = py + oy, vz = pz + oz;
+      if (posed) {  // pointcloud.cpp:321-359: p <- fl32(fl32(R p) + t)
+        const double dx = vx, dy = vy, dz = vz;
+        vx = (float)__builtin_fma((double)rt.R[2], dz, __builtin_fma((double)rt.R[1], dy, (double)rt.R[0] * dx)) + rt.t[0];
+        vy = (float)__builtin_fma((double)rt.R[5], dz, __builtin_fma((double)rt.R[4], dy, (double)rt.R[3] * dx)) + rt.t[1];
+        vz = (float)__builtin_fma((double)rt.R[8], dz, __builtin_fma((double)rt.R[7], dy, (double)rt.R[6] * dx)) + rt.t[2];
+      }
+      x[rank] = vx;
+      y[rank] = vy;
+      z[rank] = vz;
+      if (x2) {
+        x2[rank] = vx;
+        y2[rank] = vy;
+        z2[rank] = vz;
+      }
+    }
+    off += wcount[k][0] + wcount[k][1] + wcount[k][2] + wcount[k][3];
+  }
+  if (blockIdx.x == 0) {
+    const int n = im.counts[nblocks];
+    const int padded = ((n < 1 ? 1 : n) + NN_TILE - 1) / NN_TILE * NN_TILE;
+    for (int i = n + (int)threadIdx.x; i < padded; i += BP_THREADS) {
+      x[i] = y[i] = z[i] = im.pad;
+      if (x2) x2[i] = y2[i] = z2[i] = im.pad;
+    }
+  }
+}
+
+void launch_backproject_pair(const BpPair& b, int rows, int cols, float fx, float cx, float ox, float oy, float oz,
+                             const Rt& rt, int posed, int* n_out, hipStream_t s) {
+  const int npix = rows * cols;
+  const int nblocks = (npix + BP_BLOCK - 1) / BP_BLOCK;
+  hipLaunchKernelGGL(bp_count_pair_kernel, dim3(nblocks, 2), dim3(BP_THREADS), 0, s, b, npix);
+  hipLaunchKernelGGL(bp_scan_pair_kernel, dim3(2), dim3(256), 0, s, b, nblocks, n_out);
+  hipLaunchKernelGGL(bp_scatter_pair_kernel, dim3(nblocks, 2), dim3(BP_THREADS), 0, s, b, npix, cols, nblocks, fx, cx, ox,
+                     oy, oz, rt, posed);
 }
 
 void launch_backproject(const uint16_t* depth, int rows, int cols, float fx, float cx, float ox, float oy, float oz,

@@ -263,22 +263,15 @@ class Tracker {
     icpk_ctx* c = eng_.ctx();
     // icp.cpp:38-39: back-project both frames; :58-59 / :70-71: rotate by the camera
     // rotation, translate by the camera position (both clouds get the current pose)
-    int n = icpk_backproject(c, previous, rows, cols, fx_, cx_, nullptr, 1);
-    if (n < 0) return n;
-    int rc = icpk_transform_target(c, cameraRotation, cameraPosition);
-    if (rc != ICPK_OK) return rc;
-    n = icpk_backproject(c, data, rows, cols, fx_, cx_, nullptr, 0);
-    if (n < 0) return n;
-    rc = icpk_transform_source(c, cameraRotation, cameraPosition);
+    // -- one call: both uploads, 3 launches (5 with filterFrames), one host wait; the posed source is the
+    // starting point of the alignment
+    int rc = icpk_backproject_pair(c, data, previous, rows, cols, fx_, cx_, nullptr, cameraRotation, cameraPosition,
+                                   filterFrames ? 1 : 0, maxDistance, minDistance, 1, -1, -1, nullptr, nullptr);
     if (rc != ICPK_OK) return rc;
     params.max_iterations = maxIterations;
     params.threshold = threshold;
     std::memcpy(params.last_rotation, lastRotation, sizeof(lastRotation));
     std::memcpy(params.last_translation, lastTranslation, sizeof(lastTranslation));
-    // the aligned source of icpk_align starts from the cloud "as uploaded"; make the
-    // posed cloud that starting point
-    rc = icpk_commit_source(c);
-    if (rc != ICPK_OK) return rc;
     icpk_stats st;
     rc = icpk_align(c, &params, T, &st);
     if (rc < 0) return rc;
@@ -304,6 +297,10 @@ class Tracker {
     return rc;
   }
 
+  // SLAM.cpp:229 filters every frame before it reaches getTransformation; set this to have the filter run
+  // on the device inside the same call instead (SLAM.hpp:15-16 limits)
+  bool filterFrames = false;
+  int maxDistance = 25000, minDistance = 1000;
   float cameraRotation[9];
   float lastRotation[9];
   float cameraPosition[3];

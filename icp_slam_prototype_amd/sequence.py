@@ -118,11 +118,9 @@ class SequenceRunner:
                 _, self.initial_q = ground_truth.next(timestamp)
             return None
         c = self.ctx
-        c.backproject(self.previous, which=1, fx=self.fx, cx=self.cx)
-        c.transform_target(self.camera_rotation, self.camera_position)   # icp.cpp:58-59
-        c.backproject(depth, which=0, fx=self.fx, cx=self.cx)
-        c.transform_source(self.camera_rotation, self.camera_position)   # icp.cpp:70-71
-        c.commit_source()
+        # icp.cpp:38-39 back-project both frames, :58-59 / :70-71 pose them; the posed source is the
+        # starting point of the alignment (one call: icpk_backproject_pair)
+        c.backproject_pair(depth, self.previous, R=self.camera_rotation, t=self.camera_position, fx=self.fx, cx=self.cx)
         T, st, rc = c.align(last_rotation=self.last_rotation, last_translation=self.last_translation, **self.kw)
         for it in c.get_trace(max(self.kw["max_iterations"], 1)):
             self.camera_rotation = _mul3f(self.camera_rotation, _inv3f(it["R"]))   # icp.cpp:235-237

@@ -299,6 +299,20 @@ int icpk_backproject_filtered(icpk_ctx *ctx, const uint16_t *depth, int32_t rows
                               float cx, const float offset[3], int32_t which, int32_t normals_mode,
                               int32_t max_d, int32_t min_d, int32_t morph, int32_t anchor_x, int32_t anchor_y);
 
+/* The cloud set-up of icp::getTransformation for one frame pair in ONE call (icp.cpp:38-39 back-project
+ * `data` and `previous`, :58-59 / :70-71 rotate both by cameraRotation and translate by cameraPosition):
+ * depth_source = the current frame, depth_target = the previous one; offset as in icpk_backproject;
+ * R, t (both or neither) = the pose applied to every point afterwards, p <- fl32(fl32(R p) + t); filter != 0
+ * runs icpk_filter_depth_image's filter (max_d ... anchor_y) on both frames first.  Equivalent, bit for bit,
+ * to icpk_backproject[_filtered] x 2 + icpk_transform_target + icpk_transform_source + icpk_commit_source
+ * (the posed source is the starting point of the alignment), with 3-5 kernel launches instead of 25
+ * and one host wait instead of two.  *n_source / *n_target: the cloud sizes. */
+int icpk_backproject_pair(icpk_ctx *ctx, const uint16_t *depth_source, const uint16_t *depth_target,
+                          int32_t rows, int32_t cols, float fx, float cx, const float offset[3],
+                          const float R[9], const float t[3], int32_t filter, int32_t max_d, int32_t min_d,
+                          int32_t morph, int32_t anchor_x, int32_t anchor_y, int32_t *n_source,
+                          int32_t *n_target);
+
 /* ---- point-to-plane extension (BASELINE config 3; not in the reference) ---- */
 #define ICPK_NORMALS_CROSS 0     /* normalised cross product of back-projected central differences */
 #define ICPK_NORMALS_REFERENCE 1 /* SLAM.cpp:421-425 getNormalMap formula, interior pixels          */

@@ -163,3 +163,65 @@ def test_backproject_filtered_equals_filter_then_backproject(ctx, oracle):
     f = oracle.depth_range_filter(d).reshape(d.shape)
     pts, nrm = oracle.backproject_normals(f, 0)
     assert n == pts.shape[1] and np.array_equal(ctx.get_target(), pts) and np.array_equal(ctx.get_target_normals(), nrm)
+
+
+# ---------------------------------------------------------- frame-pair set-up --
+def _state(c):
+    T, st, rc = c.align(max_iterations=6, threshold=1e-6)
+    idx, dist = c.get_associations()
+    return (c.source_size, c.target_size, c.get_target().tobytes(), T.tobytes(), st.iterations, st.final_pairs, st.final_mse,
+            idx.tobytes(), dist.tobytes(), c.get_source().tobytes())
+
+
+@pytest.mark.parametrize("rows,cols,filt", [(480, 640, False), (480, 640, True), (37, 53, False), (61, 47, True), (32, 32, False)])
+def test_backproject_pair_equals_the_separate_calls(rows, cols, filt):
+    """icpk_backproject_pair (icp.cpp:38-71 in one call: 3-5 launches, one host wait) against
+    icpk_backproject[_filtered] x 2 + icpk_transform_target / _source + icpk_commit_source: clouds, the
+    alignment that follows and the aligned source, bit for bit."""
+    fx, cx = float(synth.K2_FX) * cols / 640, float(synth.K2_CX) * cols / 640
+    p = synth.kinect_pair(rows, cols, valid=0.6, seed=31, fx=fx, cx=cx, noise_sigma=0.001)
+    ds, dt = p["depth_src"].copy(), p["depth_tgt"].copy()
+    if filt:
+        ds[::5, ::3] = 30000  # beyond maxDistance: removed by the range clamp
+        dt[1::6, ::4] = 300
+    R = binding.make_rotation_matrix(2.0, -3.0, 1.5)
+    t = np.array([5, 5.5, 4.5], np.float32)
+    for pose in ((R, t), (None, None)):
+        for off in (None, [0.25, -0.5, 1.0]):
+            with binding.Context(0) as a, binding.Context(0) as b:
+                bp = (lambda c, d, w: c.backproject_filtered(d, which=w, fx=fx, cx=cx, offset=off)) if filt else \
+                     (lambda c, d, w: c.backproject(d, which=w, fx=fx, cx=cx, offset=off))
+                nt = bp(a, dt, 1)
+                if pose[0] is not None:
+                    a.transform_target(*pose)
+                ns = bp(a, ds, 0)
+                if pose[0] is not None:
+                    a.transform_source(*pose)
+                a.commit_source()
+                got = b.backproject_pair(ds, dt, R=pose[0], t=pose[1], fx=fx, cx=cx, offset=off, filter=filt)
+                assert got == (ns, nt)
+                assert a.get_source().tobytes() == b.get_source().tobytes()
+                sa, sb = _state(a), _state(b)
+                assert sa == sb
+                b.reset_source()  # the posed cloud is the starting point
+                a.reset_source()
+                assert a.get_source().tobytes() == b.get_source().tobytes()
+                # a second pair through the same context (buffers re-used, flags reset)
+                assert b.backproject_pair(dt, ds, R=pose[0], t=pose[1], fx=fx, cx=cx, offset=off, filter=filt) == (nt, ns)
+
+
+def test_backproject_pair_empty_frames_and_bad_arguments():
+    z = np.zeros((24, 40), np.uint16)
+    d = z.copy()
+    d[3:9, 5:30] = 7000
+    with binding.Context(0) as c:
+        assert c.backproject_pair(z, d) == (0, 150)
+        assert c.source_size == 0 and c.target_size == 150
+        assert c.backproject_pair(d, z) == (150, 0)
+        with pytest.raises(binding.IcpkError) as e:
+            c.align(max_iterations=3)
+        assert e.value.code == binding.E_EMPTY_TARGET
+        with pytest.raises(ValueError):
+            c.backproject_pair(d, z[:10])
+        with pytest.raises(binding.IcpkError):
+            c.backproject_pair(d, d, R=np.eye(3, dtype=np.float32), t=None)
