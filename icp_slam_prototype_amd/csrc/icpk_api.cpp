@@ -238,10 +238,20 @@ int prepare_pruned_target(icpk_ctx* ctx, NnBoxes& bx) {
   return ICPK_OK;
 }
 
-// counts / starts of the counting sorts by cell (targets: cell_start; queries: qstart)
+// counts / starts of the counting sorts by cell (targets: cell_start; queries: qstart).  The count table is
+// all zero between two sorts (the scan hands it back zeroed); a sort that did not get as far as its scan --
+// a failed launch -- leaves it marked dirty, and the next one clears all of it first.
 int ensure_scan_buffers(icpk_ctx* ctx) {
-  if (!ctx->qcount) ICPK_HIP(ctx, hipMalloc((void**)&ctx->qcount, ((size_t)GRID_MAX_CELLS + 1) * sizeof(int)));
-  if (!ctx->qstart) ICPK_HIP(ctx, hipMalloc((void**)&ctx->qstart, ((size_t)GRID_MAX_CELLS + 1) * sizeof(int)));
+  const size_t bytes = ((size_t)GRID_MAX_CELLS + 1) * sizeof(int);
+  if (!ctx->qcount) {
+    ICPK_HIP(ctx, hipMalloc((void**)&ctx->qcount, bytes));
+    ctx->qcount_dirty = true;
+  }
+  if (ctx->qcount_dirty) {
+    ICPK_HIP(ctx, hipMemsetAsync(ctx->qcount, 0, bytes, ctx->stream));
+    ctx->qcount_dirty = false;
+  }
+  if (!ctx->qstart) ICPK_HIP(ctx, hipMalloc((void**)&ctx->qstart, bytes));
   if (!ctx->scan_bsum) ICPK_HIP(ctx, hipMalloc((void**)&ctx->scan_bsum, (size_t)GRID_SCAN_BLOCKS * sizeof(int)));
   return ICPK_OK;
 }
@@ -276,19 +286,22 @@ int prepare_grid_target(icpk_ctx* ctx) {
   // scan of the counts (entry ncells = Nt), scatter into the AoS copy
   int* tcell = reinterpret_cast<int*>(ctx->sort_keys + ctx->sort_cap);
   int* tslot = ctx->sort_vals;
-  launch_grid_zero_counts(ctx->qcount, ctx->grid_info, 0, ctx->stream);
+  ctx->qcount_dirty = true;
   launch_grid_qslot(ctx->tgt.x(), ctx->tgt.y(), ctx->tgt.z(), nt, ctx->grid_info, ctx->qcount, tcell, tslot, 0,
                     ctx->stream);
   launch_grid_scan(ctx->qcount, ctx->cell_start, ctx->scan_bsum, ctx->grid_info, 0, ctx->stream);
   launch_grid_tscatter(ctx->tgt.x(), ctx->tgt.y(), ctx->tgt.z(), tcell, tslot, ctx->cell_start, nt, ctx->t4,
                        ctx->stream);
   ICPK_HIP(ctx, hipGetLastError());
+  ctx->qcount_dirty = false;
   ctx->have_grid = true;
   return ICPK_OK;
 }
 
-// query order for the grid scan: counting sort of the source by cell of the target's grid
-int enqueue_cell_order(icpk_ctx* ctx) {
+// query order for the grid scan: counting sort of the source by cell of the target's grid.
+// with_points: the scatter also writes the scan-order queries and element 0 as everybody's seed
+// (the first sweep of an alignment that has no seeds)
+int enqueue_cell_order(icpk_ctx* ctx, bool with_points) {
   const int nq = ctx->src.n;
   int rc = ensure_sort_buffers(ctx, nq);
   if (rc) return rc;
@@ -296,13 +309,32 @@ int enqueue_cell_order(icpk_ctx* ctx) {
   if (rc) return rc;
   int* qcell = reinterpret_cast<int*>(ctx->sort_keys + ctx->sort_cap);
   int* qslot = ctx->sort_vals;
-  // (locality only: the coarser table, xdiv times fewer counts to zero and scan)
-  launch_grid_zero_counts(ctx->qcount, ctx->grid_info, 1, ctx->stream);
+  // (locality only: the coarser table, xdiv times fewer counts to scan)
+  ctx->qcount_dirty = true;
   launch_grid_qslot(ctx->src.x(), ctx->src.y(), ctx->src.z(), nq, ctx->grid_info, ctx->qcount, qcell, qslot, 1,
                     ctx->stream);
   launch_grid_scan(ctx->qcount, ctx->qstart, ctx->scan_bsum, ctx->grid_info, 1, ctx->stream);
-  launch_grid_qscatter(qcell, qslot, ctx->qstart, nq, ctx->qperm, ctx->stream);
+  launch_grid_qscatter(qcell, qslot, ctx->qstart, nq, ctx->qperm, ctx->src.x(), ctx->src.y(), ctx->src.z(), ctx->tgt.x(),
+                       ctx->tgt.y(), ctx->tgt.z(), with_points ? ctx->qm4 : nullptr, ctx->sp_in, ctx->seed_m, ctx->stream);
   ICPK_HIP(ctx, hipGetLastError());
+  ctx->qcount_dirty = false;
+  return ICPK_OK;
+}
+
+// scan-order copies of the queries and of their seed points (grid scan)
+int ensure_query_points(icpk_ctx* ctx, int nq) {
+  if (nq <= ctx->qm4_cap) return ICPK_OK;
+  for (float4** pp : {&ctx->qm4, &ctx->sp_in, &ctx->sp_out}) {
+    if (*pp) ICPK_HIP(ctx, hipFree(*pp));
+    *pp = nullptr;
+  }
+  ctx->qm4_cap = 0;
+  const size_t bytes = ((size_t)round_up(nq, NN_TILE) + 64) * sizeof(float4);
+  ICPK_HIP(ctx, hipMalloc((void**)&ctx->qm4, bytes));
+  ICPK_HIP(ctx, hipMalloc((void**)&ctx->sp_in, bytes));
+  ICPK_HIP(ctx, hipMalloc((void**)&ctx->sp_out, bytes));
+  ctx->qm4_cap = round_up(nq, NN_TILE);
+  ctx->grid_chain = false;
   return ICPK_OK;
 }
 
@@ -327,18 +359,21 @@ int prepare_sorted_sweep(icpk_ctx* ctx, int nn_mode, NnArgs& a, NnBoxes& bx, int
     bx.oy = ctx->tgt.y();
     bx.oz = ctx->tgt.z();
     rc = prepare_grid_target(ctx);
+    if (!rc) rc = ensure_query_points(ctx, nq);
   } else {
     rc = prepare_pruned_target(ctx, bx);
   }
   if (rc) return rc;
   bool new_order = false;
+  bool points_written = false;  // qm4 / sp_in / seed_m already hold this sweep's queries and seeds
   const int want_kind = nn_mode == ICPK_NN_GRID ? 2 : 1;
   if (!ctx->have_qperm || !ctx->have_seed || ctx->qperm_kind != want_kind) {
     // query order (once per alignment), from the source at its current pose: Morton order
     // for the pruned scan (the unsorted Morton keys of the queries stay in sort_keys[0..nq)
     // for its first-sweep seeds), order by grid cell (a cheaper counting sort) for the grid scan
     if (nn_mode == ICPK_NN_GRID) {
-      rc = enqueue_cell_order(ctx);
+      points_written = !ctx->have_seed;
+      rc = enqueue_cell_order(ctx, points_written);
     } else {
       rc = enqueue_morton_order(ctx, ctx->src, ctx->qperm);
     }
@@ -358,7 +393,7 @@ int prepare_sorted_sweep(icpk_ctx* ctx, int nn_mode, NnArgs& a, NnBoxes& bx, int
   } else if (nn_mode == ICPK_NN_GRID) {
     // first sweep of the grid scan: the reference's own literal seed, element 0 (icp.cpp:572);
     // the expanding search does not depend on the seed's quality
-    launch_fill_u64(ctx->seed_m, nq, 0ull, nullptr, ctx->stream);
+    if (!points_written) launch_fill_u64(ctx->seed_m, nq, 0ull, nullptr, ctx->stream);
     recheck = 1;
   } else {  // first sweep: the target with the nearest Morton code; loose, so re-check lazily
     launch_seed_morton(ctx->sort_keys, ctx->qperm, nq, ctx->src.x(), ctx->src.y(), ctx->src.z(), ctx->tkeys,
@@ -372,22 +407,9 @@ int prepare_sorted_sweep(icpk_ctx* ctx, int nn_mode, NnArgs& a, NnBoxes& bx, int
   a.tiles_per_chunk = a.nt_pad / NN_TILE;
   a.best = ctx->best;
   if (nn_mode == ICPK_NN_GRID) {
-    if (nq > ctx->qm4_cap) {
-      for (float4** pp : {&ctx->qm4, &ctx->sp_in, &ctx->sp_out}) {
-        if (*pp) ICPK_HIP(ctx, hipFree(*pp));
-        *pp = nullptr;
-      }
-      ctx->qm4_cap = 0;
-      const size_t bytes = ((size_t)round_up(nq, NN_TILE) + 64) * sizeof(float4);
-      ICPK_HIP(ctx, hipMalloc((void**)&ctx->qm4, bytes));
-      ICPK_HIP(ctx, hipMalloc((void**)&ctx->sp_in, bytes));
-      ICPK_HIP(ctx, hipMalloc((void**)&ctx->sp_out, bytes));
-      ctx->qm4_cap = round_up(nq, NN_TILE);
-      ctx->grid_chain = false;
-    }
     // inside a device loop the grid sweeps keep qm4 / the seed points current themselves;
     // anywhere else the source may have been moved by other kernels: gather afresh
-    if (!(ctx->st_active && ctx->grid_chain))
+    if (!(ctx->st_active && ctx->grid_chain) && !points_written)
       launch_grid_query_points(ctx->src.x(), ctx->src.y(), ctx->src.z(), ctx->qperm, nq, ctx->seed_m, bx.ox, bx.oy,
                                bx.oz, ctx->qm4, ctx->sp_in, ctx->stream);
   }

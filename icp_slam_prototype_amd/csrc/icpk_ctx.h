@@ -115,6 +115,7 @@ struct icpk_ctx {
   struct icpk_comm_state* comm = nullptr;
   int* qcount = nullptr;     // query counting sort by cell: counts and starts, GRID_MAX_CELLS + 1 each
   int* qstart = nullptr;
+  bool qcount_dirty = false; // a counting sort was cut short: clear the whole count table before the next one
   int* scan_bsum = nullptr;  // block sums of the cell-count scans (GRID_SCAN_BLOCKS ints)
   int loop_nact = icpk::NSUM;      // device loop: sums the running alignment's step consumes (NSUM_REF or NSUM)
   int profile_phase = 0;     // alignments profiled so far (offsets the sampled launches, see profile_stride)

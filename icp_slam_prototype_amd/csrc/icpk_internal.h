@@ -118,10 +118,12 @@ void launch_grid_tscatter(const float* x, const float* y, const float* z, const 
                           const int* cell_start, int n, float4* t4, hipStream_t s);
 void launch_grid_qslot(const float* x, const float* y, const float* z, int n, const GridInfo* g, int* count, int* qcell,
                        int* qslot, int coarse, hipStream_t s);
-void launch_grid_qscatter(const int* qcell, const int* qslot, const int* qstart, int n, int* qperm, hipStream_t s);
+// qm4 != nullptr: also the scan-order queries, element 0 as every query's seed point and seed key
+void launch_grid_qscatter(const int* qcell, const int* qslot, const int* qstart, int n, int* qperm, const float* qx,
+                          const float* qy, const float* qz, const float* ox, const float* oy, const float* oz,
+                          float4* qm4, float4* sp, nn_key_t* seed_m, hipStream_t s);
 constexpr int GRID_SCAN_BLOCKS = (GRID_MAX_CELLS + 1 + 2047) / 2048 + 1;  // scratch ints of launch_grid_scan
-void launch_grid_zero_counts(int* count, const GridInfo* g, int coarse, hipStream_t s);
-void launch_grid_scan(const int* in, int* out, int* bsum, const GridInfo* g, int coarse, hipStream_t s);
+void launch_grid_scan(int* count, int* out, int* bsum, const GridInfo* g, int coarse, hipStream_t s);  // count[] left zero
 // one pair's arguments of a grid sweep (K1d); see nn_grid_body
 struct GridSweepArgs {
   float *qx, *qy, *qz;  // the caller's source planes (kept in step when K3 is fused)

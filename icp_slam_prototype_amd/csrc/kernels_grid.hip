@@ -153,31 +153,42 @@ __global__ void grid_qslot_kernel(const float* __restrict__ x, const float* __re
   qslot[i] = atomicAdd(&count[c], 1);
 }
 
+// qm4 != nullptr: the first sweep of an alignment without seeds -- the queries in scan order (x, y, z, index),
+// the reference's literal seed (element 0, icp.cpp:572) as a point and as a key, written here instead of by
+// a zero fill and grid_query_points_kernel afterwards (two launches less per alignment)
 __global__ void grid_qscatter_kernel(const int* __restrict__ qcell, const int* __restrict__ qslot,
-                                     const int* __restrict__ qstart, int n, int* __restrict__ qperm) {
+                                     const int* __restrict__ qstart, int n, int* __restrict__ qperm,
+                                     const float* __restrict__ qx, const float* __restrict__ qy,
+                                     const float* __restrict__ qz, const float* __restrict__ ox,
+                                     const float* __restrict__ oy, const float* __restrict__ oz,
+                                     float4* __restrict__ qm4, float4* __restrict__ sp,
+                                     nn_key_t* __restrict__ seed_m) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) qperm[qstart[qcell[i]] + qslot[i]] = i;
+  if (i >= n) return;
+  const int ip = qstart[qcell[i]] + qslot[i];
+  qperm[ip] = i;
+  if (qm4) {
+    qm4[ip] = make_float4(qx[i], qy[i], qz[i], __int_as_float(i));
+    sp[ip] = make_float4(ox[0], oy[0], oz[0], __int_as_float(0));
+    seed_m[ip] = 0ull;
+  }
 }
 
-// ---- device-sized zero fill and exclusive scan of the cell counts -------------------------
+// ---- device-sized exclusive scan of the cell counts ----------------------------------------
 // The number of cells lives in GridInfo ON THE DEVICE; these kernels read it there, so the whole
 // grid build is enqueued without a host round trip (the frame-batch mode builds the grids of the
 // next group while the current group's loop keeps the GPU busy: a host wait there costs
 // milliseconds).  Launch geometry covers GRID_MAX_CELLS + 1; workgroups beyond the actual size
-// leave at once.  Scan: 2048 counts per workgroup (256 lanes x 8), block sums, one workgroup
-// scans the <= 2049 block sums, then every block scans its own counts from its offset.
+// leave at once.  Scan in two launches: 2048 counts per workgroup (256 lanes x 8) -> block sums;
+// then every block adds up the sums of the blocks before it (<= 2049 values, 8 per lane) and scans
+// its own counts from there -- and leaves them ZERO: the count table is all zero between two sorts
+// (hipMemset at allocation), so no sort starts with a zero-fill launch.
 constexpr int GSCAN_ITEMS = 8;
 constexpr int GSCAN_TILE = 256 * GSCAN_ITEMS;
 constexpr int GSCAN_MAX_BLOCKS = (GRID_MAX_CELLS + 1 + GSCAN_TILE - 1) / GSCAN_TILE;  // 2049
 
 __device__ __forceinline__ int grid_table_size(const GridInfo* __restrict__ gi, int coarse) {
   return (coarse ? gi->ncells_q : gi->ncells) + 1;
-}
-
-__global__ __launch_bounds__(256) void grid_zero_counts_kernel(int* __restrict__ count,
-                                                               const GridInfo* __restrict__ gi, int coarse) {
-  const int n = grid_table_size(gi, coarse);
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) count[i] = 0;
 }
 
 __device__ __forceinline__ int block_sum_256(int v, int* sh) {  // sum over the 256 lanes, in every lane
@@ -207,48 +218,19 @@ __global__ __launch_bounds__(256) void grid_scan_sums_kernel(const int* __restri
   if (threadIdx.x == 0) bsum[blockIdx.x] = t;
 }
 
-__global__ __launch_bounds__(1024) void grid_scan_offsets_kernel(int* __restrict__ bsum,
-                                                                 const GridInfo* __restrict__ gi, int coarse) {
-  // exclusive scan of the nb <= 2049 block sums in place: 3 per lane, wave scan, 16 wave totals
-  __shared__ int wtot[16];
-  const int n = grid_table_size(gi, coarse);
-  const int nb = (n + GSCAN_TILE - 1) / GSCAN_TILE;
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  int a[3], s = 0;
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const int i = 3 * t + k;
-    a[k] = i < nb ? bsum[i] : 0;
-    s += a[k];
-  }
-  int inc = s;  // inclusive scan over the wave
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const int o = __shfl_up(inc, d, 64);
-    if (lane >= d) inc += o;
-  }
-  if (lane == 63) wtot[wave] = inc;
-  __syncthreads();
-  int woff = 0;
-  for (int w = 0; w < wave; ++w) woff += wtot[w];
-  int run = woff + inc - s;
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const int i = 3 * t + k;
-    if (i < nb) bsum[i] = run;
-    run += a[k];
-  }
-}
-
-__global__ __launch_bounds__(256) void grid_scan_apply_kernel(const int* __restrict__ in,
-                                                              const GridInfo* __restrict__ gi,
-                                                              const int* __restrict__ boff, int* __restrict__ out,
+__global__ __launch_bounds__(256) void grid_scan_apply_kernel(int* __restrict__ in, const GridInfo* __restrict__ gi,
+                                                              const int* __restrict__ bsum, int* __restrict__ out,
                                                               int coarse) {
   __shared__ int wtot[4];
+  __shared__ int sh[4];
   const int n = grid_table_size(gi, coarse);
   const int base = blockIdx.x * GSCAN_TILE;
   if (base >= n) return;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  // this block's offset: the sums of the blocks before it
+  int before = 0;
+  for (int b = t; b < (int)blockIdx.x; b += 256) before += bsum[b];
+  const int boff = block_sum_256(before, sh);
   // lane t owns the 8 consecutive counts base + 8 t .. base + 8 t + 7
   int a[GSCAN_ITEMS], s = 0;
 #pragma unroll
@@ -265,25 +247,24 @@ __global__ __launch_bounds__(256) void grid_scan_apply_kernel(const int* __restr
   }
   if (lane == 63) wtot[wave] = inc;
   __syncthreads();
-  int run = boff[blockIdx.x] + inc - s;
+  int run = boff + inc - s;
   for (int w = 0; w < wave; ++w) run += wtot[w];
 #pragma unroll
   for (int k = 0; k < GSCAN_ITEMS; ++k) {
     const int i = base + GSCAN_ITEMS * t + k;
-    if (i < n) out[i] = run;
+    if (i < n) {
+      out[i] = run;
+      in[i] = 0;  // the table is handed back all zero
+    }
     run += a[k];
   }
 }
 
-// coarse = 1: the table of the query order (ncells_q entries), else the targets' (ncells)
-void launch_grid_zero_counts(int* count, const GridInfo* g, int coarse, hipStream_t s) {
-  hipLaunchKernelGGL(grid_zero_counts_kernel, dim3(512), dim3(256), 0, s, count, g, coarse);
-}
-// out[i] = sum of in[0 .. i) for i in [0, size]; bsum: GRID_SCAN_BLOCKS ints of scratch
-void launch_grid_scan(const int* in, int* out, int* bsum, const GridInfo* g, int coarse, hipStream_t s) {
-  hipLaunchKernelGGL(grid_scan_sums_kernel, dim3(GSCAN_MAX_BLOCKS), dim3(256), 0, s, in, g, bsum, coarse);
-  hipLaunchKernelGGL(grid_scan_offsets_kernel, dim3(1), dim3(1024), 0, s, bsum, g, coarse);
-  hipLaunchKernelGGL(grid_scan_apply_kernel, dim3(GSCAN_MAX_BLOCKS), dim3(256), 0, s, in, g, bsum, out, coarse);
+// coarse = 1: the table of the query order (ncells_q entries), else the targets' (ncells).
+// out[i] = sum of count[0 .. i) for i in [0, size]; count[] is zero afterwards; bsum: GRID_SCAN_BLOCKS ints
+void launch_grid_scan(int* count, int* out, int* bsum, const GridInfo* g, int coarse, hipStream_t s) {
+  hipLaunchKernelGGL(grid_scan_sums_kernel, dim3(GSCAN_MAX_BLOCKS), dim3(256), 0, s, count, g, bsum, coarse);
+  hipLaunchKernelGGL(grid_scan_apply_kernel, dim3(GSCAN_MAX_BLOCKS), dim3(256), 0, s, count, g, bsum, out, coarse);
 }
 
 // targets into the AoS copy (x, y, z, original index), one 16-byte load per candidate
@@ -308,9 +289,12 @@ void launch_grid_qslot(const float* x, const float* y, const float* z, int n, co
   hipLaunchKernelGGL(grid_qslot_kernel, dim3((n + 255) / 256), dim3(256), 0, s, x, y, z, n, g, count, qcell, qslot,
                      coarse);
 }
-void launch_grid_qscatter(const int* qcell, const int* qslot, const int* qstart, int n, int* qperm, hipStream_t s) {
+void launch_grid_qscatter(const int* qcell, const int* qslot, const int* qstart, int n, int* qperm, const float* qx,
+                          const float* qy, const float* qz, const float* ox, const float* oy, const float* oz,
+                          float4* qm4, float4* sp, nn_key_t* seed_m, hipStream_t s) {
   if (n <= 0) return;
-  hipLaunchKernelGGL(grid_qscatter_kernel, dim3((n + 255) / 256), dim3(256), 0, s, qcell, qslot, qstart, n, qperm);
+  hipLaunchKernelGGL(grid_qscatter_kernel, dim3((n + 255) / 256), dim3(256), 0, s, qcell, qslot, qstart, n, qperm, qx, qy,
+                     qz, ox, oy, oz, qm4, sp, seed_m);
 }
 
 int grid_bounds_parts(int n) {  // one 1024-thread block per 2048 points, at most GRID_BOUNDS_PARTS
