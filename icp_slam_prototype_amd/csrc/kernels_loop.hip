@@ -44,12 +44,10 @@ __device__ __forceinline__ void tree_stage2(const double* __restrict__ partial, 
 #pragma unroll
   for (int s = 0; s < NACT; ++s) v[s] = tid < nblocks ? partial[s * RED_MAX_BLOCKS + tid] : 0.0;  // [sum][block]: coalesced
   if (tid < nblocks) c = pcount[tid];
-  wave_butterfly<NACT>(v, c);
-  if (lane == 0) {
-#pragma unroll
-    for (int s = 0; s < NACT; ++s) ws[wave][s] = v[s];
-    wc[wave] = c;
-  }
+  double u[WaveScatter<NACT>::H2];
+  wave_reduce_scatter<NACT>(v, u, c);
+  wave_scatter_store<NACT>(u, lane, ws[wave]);
+  if (lane == 0) wc[wave] = c;
   __syncthreads();
   if (tid == 0) {
 #pragma unroll

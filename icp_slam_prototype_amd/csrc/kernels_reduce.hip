@@ -82,18 +82,16 @@ __device__ __forceinline__ void assoc_reduce_body(
   }
 
   if (v[12] > -1.0) RED_STAMP(1);  // loads and accumulation done
-  // wave64 butterfly: every lane ends with the same value; order 32,16,...,1
-  wave_butterfly<NACT>(v, cnt);
-  if (v[12] > -1.0) RED_STAMP(2);  // butterfly done
+  // the canonical wave64 tree (order 32, 16, ..., 1) as a reduce-scatter: wave_sum.h
+  double u[WaveScatter<NACT>::H2];
+  wave_reduce_scatter<NACT>(v, u, cnt);
+  if (u[0] > -1.0) RED_STAMP(2);  // butterfly done
 
   __shared__ double ws[RED_THREADS / 64][NACT];
   __shared__ int wc[RED_THREADS / 64];
   const int wave = tid >> 6, lane = tid & 63;
-  if (lane == 0) {
-#pragma unroll
-    for (int s = 0; s < NACT; ++s) ws[wave][s] = v[s];
-    wc[wave] = cnt;
-  }
+  wave_scatter_store<NACT>(u, lane, ws[wave]);
+  if (lane == 0) wc[wave] = cnt;
   __syncthreads();
   if (tid < NACT) partial[tid * RED_MAX_BLOCKS + block] = ((ws[0][tid] + ws[1][tid]) + ws[2][tid]) + ws[3][tid];
   if (tid == NACT) pcount[block] = wc[0] + wc[1] + wc[2] + wc[3];
@@ -173,15 +171,13 @@ __global__ __launch_bounds__(RED_THREADS) void p2l_reduce_kernel(
       }
     }
   }
-  wave_butterfly<NP2L>(v, cnt);
+  double u[WaveScatter<NP2L>::H2];
+  wave_reduce_scatter<NP2L>(v, u, cnt);
   __shared__ double ws[RED_THREADS / 64][NP2L];
   __shared__ int wc[RED_THREADS / 64];
   const int wave = tid >> 6, lane = tid & 63;
-  if (lane == 0) {
-#pragma unroll
-    for (int s = 0; s < NP2L; ++s) ws[wave][s] = v[s];
-    wc[wave] = cnt;
-  }
+  wave_scatter_store<NP2L>(u, lane, ws[wave]);
+  if (lane == 0) wc[wave] = cnt;
   __syncthreads();
   if (tid < NP2L) partial[tid * RED_MAX_BLOCKS + blockIdx.x] = ((ws[0][tid] + ws[1][tid]) + ws[2][tid]) + ws[3][tid];
   if (tid == NP2L) pcount[blockIdx.x] = wc[0] + wc[1] + wc[2] + wc[3];
