@@ -170,7 +170,10 @@ ICPK_HD bool polar3(const double A[9], double Q[9]) {
     if (!(ad >= 1e-30) || !(ad <= 1e30)) return false;
     const int ed = exp2_floor(ad);                                  // |det| in [2^ed, 2^(ed+1))
     const int eg = ed >= 0 ? -((ed + 1) / 3) : ((1 - ed) / 3);     // ~ -ed/3; 0 for |det| in [1/2, 4)
-    const bool last = it > 0 && eg == 0 && ad - 1.0 <= 1e-8;  // (it > 0: Q is then a Newton iterate)
+    // (it > 0: Q is then a Newton iterate, every singular value is >= 1 and |det| - 1 bounds their excess e;
+    // the step below maps 1 + e to 1 + e^2 / 2: 5e-11 from 1e-5, three decades below the float32 the rotation
+    // is delivered in and below the 1e-8 the pinned Kabsch vectors are held to)
+    const bool last = it > 0 && eg == 0 && ad - 1.0 <= 1e-5;
     const double hg = pow2i(eg - 1);                 // g / 2
     const double hinv = 0.5 / (det * pow2i(eg));     // 1 / (2 g det)
     for (int k = 0; k < 9; ++k) Q[k] = __builtin_fma(hg, Q[k], hinv * c[k]);
