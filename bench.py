@@ -204,6 +204,8 @@ def cpu_baseline_child(workload):
                   f"full reduce/solve/transform; oracle/icp_oracle.c, gcc -O2",
         "nn_s_per_sweep": t_nn, "gpairs_per_s": nq * float(nt) / t_nn / 1e9, "sample_spread": spread,
         "one_thread_ns_per_pair": ns_per_pair_1t,
+        # (a noisy neighbour on the box shows up as spread: the fastest sample is what the cores can do)
+        "fastest_sample_iter_s": 1.0 / (min(samples) + t_rest),
         "host": {"model": topo["model"], "sockets": topo["sockets"], "cores_per_socket": topo["cores_per_socket"],
                  "threads_per_core": topo["threads_per_core"], "logical_cpus": topo["logical_cpus"],
                  "cgroup_cpu_quota": topo["quota_cpus"]},
