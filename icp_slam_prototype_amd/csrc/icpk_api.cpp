@@ -268,9 +268,11 @@ int prepare_grid_target(icpk_ctx* ctx) {
   if (!ctx->cell_start) ICPK_HIP(ctx, hipMalloc((void**)&ctx->cell_start, ((size_t)GRID_MAX_CELLS + 1) * sizeof(int)));
   if (nt > ctx->t4_cap) {
     if (ctx->t4) ICPK_HIP(ctx, hipFree(ctx->t4));
-    ctx->t4 = nullptr;
+    if (ctx->o4) ICPK_HIP(ctx, hipFree(ctx->o4));
+    ctx->t4 = ctx->o4 = nullptr;
     ctx->t4_cap = 0;
     ICPK_HIP(ctx, hipMalloc((void**)&ctx->t4, ((size_t)round_up(nt, NN_TILE) + 64) * sizeof(float4)));
+    ICPK_HIP(ctx, hipMalloc((void**)&ctx->o4, ((size_t)round_up(nt, NN_TILE) + 64) * sizeof(float4)));
     ctx->t4_cap = round_up(nt, NN_TILE);
     ctx->have_grid = false;
   }
@@ -290,7 +292,7 @@ int prepare_grid_target(icpk_ctx* ctx) {
   launch_grid_qslot(ctx->tgt.x(), ctx->tgt.y(), ctx->tgt.z(), nt, ctx->grid_info, ctx->qcount, tcell, tslot, 0,
                     ctx->stream);
   launch_grid_scan(ctx->qcount, ctx->cell_start, ctx->scan_bsum, ctx->grid_info, 0, ctx->stream);
-  launch_grid_tscatter(ctx->tgt.x(), ctx->tgt.y(), ctx->tgt.z(), tcell, tslot, ctx->cell_start, nt, ctx->t4,
+  launch_grid_tscatter(ctx->tgt.x(), ctx->tgt.y(), ctx->tgt.z(), tcell, tslot, ctx->cell_start, nt, ctx->t4, ctx->o4,
                        ctx->stream);
   ICPK_HIP(ctx, hipGetLastError());
   ctx->qcount_dirty = false;
@@ -570,7 +572,7 @@ int enqueue_nn(icpk_ctx* ctx, int nn_mode, hipEvent_t ev0 = nullptr, hipEvent_t 
 int enqueue_reduce(icpk_ctx* ctx, float max_dist) {
   const int nq = ctx->src.n;
   launch_assoc_reduce(ctx->best, ctx->src.x(), ctx->src.y(), ctx->src.z(), nq, ctx->tgt.x(), ctx->tgt.y(), ctx->tgt.z(),
-                      max_dist, ctx->st_active ? nullptr : ctx->idx, ctx->st_active ? nullptr : ctx->dist, ctx->partial,
+                      ctx->have_grid ? ctx->o4 : nullptr, max_dist, ctx->st_active ? nullptr : ctx->idx, ctx->st_active ? nullptr : ctx->dist, ctx->partial,
                       ctx->pcount, ctx->st_active ? nullptr : ctx->red_out,
                       ctx->st_active, ctx->st_active ? ctx->loop_nact : NSUM, ctx->stream);
   ICPK_HIP(ctx, hipGetLastError());
@@ -730,7 +732,7 @@ void icpk_destroy(icpk_ctx* ctx) {
   for (hipEvent_t e : {ctx->ready_ev, ctx->group_ev[0], ctx->group_ev[1]})
     if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : ctx->events) (void)hipEventDestroy(e);
-  void* dev[] = {ctx->qcount, ctx->qstart, ctx->scan_bsum, ctx->qm4, ctx->sp_in, ctx->sp_out, ctx->grid_info, ctx->grid_bounds, ctx->cell_start, ctx->t4, ctx->best_m, ctx->seed_m, ctx->st_dev, ctx->sorted.base, ctx->tkeys, ctx->tperm, ctx->qperm, ctx->bounds, ctx->sort_keys, ctx->sort_vals, ctx->sort_temp,
+  void* dev[] = {ctx->qcount, ctx->qstart, ctx->scan_bsum, ctx->qm4, ctx->sp_in, ctx->sp_out, ctx->grid_info, ctx->grid_bounds, ctx->cell_start, ctx->t4, ctx->o4, ctx->best_m, ctx->seed_m, ctx->st_dev, ctx->sorted.base, ctx->tkeys, ctx->tperm, ctx->qperm, ctx->bounds, ctx->sort_keys, ctx->sort_vals, ctx->sort_temp,
                  ctx->nrm.base, ctx->boxes, ctx->dec.base, ctx->tgt.base, ctx->src0.base, ctx->src.base, ctx->best,      ctx->seed,     ctx->idx,
                  ctx->dist,     ctx->partial,   ctx->pcount,   ctx->red_out,   ctx->depth_dev, ctx->depth_flt, ctx->ks_buf, ctx->bp_counts};
   for (void* p : dev)
@@ -1494,6 +1496,7 @@ ReduceArgs slot_reduce_args(const icpk_ctx* sl) {
   r.tx = sl->tgt.x();
   r.ty = sl->tgt.y();
   r.tz = sl->tgt.z();
+  r.o4 = sl->have_grid ? sl->o4 : nullptr;
   r.partial = sl->partial;
   r.pcount = sl->pcount;
   r.st = sl->st_dev;

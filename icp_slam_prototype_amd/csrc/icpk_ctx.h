@@ -98,6 +98,7 @@ struct icpk_ctx {
   float* grid_bounds = nullptr;
   int* cell_start = nullptr;  // GRID_MAX_CELLS + 1
   float4* t4 = nullptr;
+  float4* o4 = nullptr;      // the target in the CALLER's order as (x, y, z, 0): K2's gather of the matched point is one 16-byte load (valid while have_grid)
   float4* qm4 = nullptr;     // queries in scan order (x, y, z, original index)
   float4* sp_in = nullptr;   // seeds as points, scan order: read by the next grid sweep
   float4* sp_out = nullptr;  // ... written by it

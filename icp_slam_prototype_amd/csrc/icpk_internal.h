@@ -115,7 +115,7 @@ struct GridInfo {
 void launch_grid_bounds(const float* x, const float* y, const float* z, int n, float* fb, hipStream_t s);
 void launch_grid_info(const float* fb, int n, float ppc, int xdiv, GridInfo* g, hipStream_t s);
 void launch_grid_tscatter(const float* x, const float* y, const float* z, const int* tcell, const int* tslot,
-                          const int* cell_start, int n, float4* t4, hipStream_t s);
+                          const int* cell_start, int n, float4* t4, float4* o4, hipStream_t s);
 void launch_grid_qslot(const float* x, const float* y, const float* z, int n, const GridInfo* g, int* count, int* qcell,
                        int* qslot, int coarse, hipStream_t s);
 // qm4 != nullptr: also the scan-order queries, element 0 as every query's seed point and seed key
@@ -215,15 +215,17 @@ void launch_reduce_final(const double* partial, const int* pcount, int nblocks, 
 // out: nsum doubles followed by one int64 count ((NSUM_MAX + 1) x 8 bytes).
 // out == nullptr: only the per-block partials are produced (the device loop sums them
 // in launch_loop_step); stop: device-loop stop flags or nullptr
+// o4: the target as caller-order (x, y, z, 0) points or nullptr (then tx / ty / tz are gathered)
 void launch_assoc_reduce(const nn_key_t* best, const float* ax, const float* ay, const float* az, int nq,
-                         const float* tx, const float* ty, const float* tz, float max_dist, int32_t* idx_out,
-                         float* dist_out, double* partial, int* pcount, double* out, LoopState* st, int nact,
-                         hipStream_t s);
+                         const float* tx, const float* ty, const float* tz, const float4* o4, float max_dist,
+                         int32_t* idx_out, float* dist_out, double* partial, int* pcount, double* out, LoopState* st,
+                         int nact, hipStream_t s);
 // one pair's arguments of K2 inside a device loop (no idx/dist unpacking, no final stage)
 struct ReduceArgs {
   const nn_key_t* best;
   const float *ax, *ay, *az;
   const float *tx, *ty, *tz;
+  const float4* o4;  // or nullptr
   double* partial;
   int* pcount;
   LoopState* st;

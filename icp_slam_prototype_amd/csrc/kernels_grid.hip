@@ -267,20 +267,24 @@ void launch_grid_scan(int* count, int* out, int* bsum, const GridInfo* g, int co
   hipLaunchKernelGGL(grid_scan_apply_kernel, dim3(GSCAN_MAX_BLOCKS), dim3(256), 0, s, count, g, bsum, out, coarse);
 }
 
-// targets into the AoS copy (x, y, z, original index), one 16-byte load per candidate
+// targets into the AoS copy (x, y, z, original index), one 16-byte load per candidate -- and, in the
+// caller's order, into o4 (x, y, z, 0): K2 fetches a matched point with one load instead of three
 __global__ void grid_tscatter_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                      const float* __restrict__ z, const int* __restrict__ tcell,
                                      const int* __restrict__ tslot, const int* __restrict__ cell_start, int n,
-                                     float4* __restrict__ t4) {
+                                     float4* __restrict__ t4, float4* __restrict__ o4) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) t4[cell_start[tcell[i]] + tslot[i]] = make_float4(x[i], y[i], z[i], __int_as_float(i));
+  if (i >= n) return;
+  const float px = x[i], py = y[i], pz = z[i];
+  t4[cell_start[tcell[i]] + tslot[i]] = make_float4(px, py, pz, __int_as_float(i));
+  o4[i] = make_float4(px, py, pz, 0.f);
 }
 
 void launch_grid_tscatter(const float* x, const float* y, const float* z, const int* tcell, const int* tslot,
-                          const int* cell_start, int n, float4* t4, hipStream_t s) {
+                          const int* cell_start, int n, float4* t4, float4* o4, hipStream_t s) {
   if (n <= 0) return;
   hipLaunchKernelGGL(grid_tscatter_kernel, dim3((n + 255) / 256), dim3(256), 0, s, x, y, z, tcell, tslot, cell_start,
-                     n, t4);
+                     n, t4, o4);
 }
 
 void launch_grid_qslot(const float* x, const float* y, const float* z, int n, const GridInfo* g, int* count, int* qcell,
