@@ -408,6 +408,7 @@ def bench_single(args, torch, dev, gpu_index):
         out["extra"] = {}
         for name, iters, steps in (("kinect640x480_dense", 20, 10), ("dense1m", 50, 4)):
             out["extra"][f"{name}_{iters}iters"] = extra_workload(args, torch, dev, gpu_index, name, iters, steps)
+        out["extra"]["kinect_v2_512x424_point_to_plane_20iters"] = extra_point_to_plane(args, torch, dev, gpu_index)
         out["extra"]["tracker_path"] = tracker_path(gpu_index)
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.workload)
@@ -480,6 +481,30 @@ def extra_workload(args, torch, dev, gpu_index, name, iters, steps):
     return {"workload": f"{name}: {nq} x {nt} points, {iters} fixed iterations per step, {steps} steps",
             "value": iters_done / elapsed, "unit": "iter/s", "ms_per_step": elapsed / steps * 1e3,
             "nn_mpoints_per_s": nn_launches * nq / elapsed / 1e6, "roofline": phys, "roofline_algorithmic": yard}
+
+
+def extra_point_to_plane(args, torch, dev, gpu_index, iters=20, steps=10):
+    """BASELINE configs[2], driver-visible: Kinect v2 512x424 pair, surface normals computed on the device
+    from the target's depth image, point-to-plane error accumulation (K5) and solve, grid NN."""
+    from icp_slam_prototype_amd import binding, synth
+
+    w = make_workload("kinect_v2_512x424", 2)
+    src_d, tgt_d = upload(torch, dev, w["source"]), upload(torch, dev, w["target"])
+    torch.cuda.synchronize()
+    nq, nt = src_d.shape[1], tgt_d.shape[1]
+    ctx = binding.Context(gpu_index)
+    set_clouds_device(ctx, src_d, tgt_d)
+    ctx.backproject_with_normals(w["depth_tgt"], binding.NORMALS_CROSS, offset=[5, 5, 5], fx=float(synth.K2_FX),
+                                 cx=float(synth.K2_CX))
+    assert ctx.target_size == nt
+    params = binding.default_params(max_iterations=iters, fixed_iterations=1, max_nn_dist=0.3,
+                                    solve=binding.SOLVE_POINT_TO_PLANE, nn_mode=binding.NN_GRID)
+    elapsed, iters_done, nn_launches, nn_timed, nn_ms = timed_alignments(torch, ctx, params, steps, 2, torch.cuda.synchronize)
+    ctx.close()
+    return {"workload": f"kinect_v2_512x424 (BASELINE configs[2]): {nq} x {nt} points with target normals, point-to-plane, "
+                        f"{iters} fixed iterations per step, {steps} steps",
+            "value": iters_done / elapsed, "unit": "iter/s", "ms_per_step": elapsed / steps * 1e3,
+            "nn_mpoints_per_s": nn_launches * nq / elapsed / 1e6, "nn_kernel_avg_launch_ms": nn_ms / max(nn_timed, 1)}
 
 
 def tracker_path(gpu_index):
