@@ -10,9 +10,14 @@ p = synth.kinect_pair(480, 640, valid=0.30, seed=2)
 ctx = binding.Context(0)
 ctx.set_target(p["target"]); ctx.set_source(p["source"])
 L = binding.load()
-for solve in (binding.SOLVE_REFERENCE,):
+p2l = "--p2l" in sys.argv
+if p2l:  # BASELINE configs[2]: Kinect v2 pair, target normals from the depth image
+    p = synth.kinect_pair(424, 512, valid=1.0, seed=2, fx=synth.K2_FX, cx=synth.K2_CX)
+    ctx.set_target(p["target"]); ctx.set_source(p["source"])
+    ctx.backproject_with_normals(p["depth_tgt"], binding.NORMALS_CROSS, offset=[5, 5, 5], fx=float(synth.K2_FX), cx=float(synth.K2_CX))
+for solve in ((binding.SOLVE_POINT_TO_PLANE,) if p2l else (binding.SOLVE_REFERENCE,)):
     for _ in range(3):
-        ctx.align(max_iterations=20, fixed_iterations=1, solve=solve)
+        ctx.align(max_iterations=20, fixed_iterations=1, solve=solve, max_nn_dist=0.3 if p2l else 0.75)
     buf = np.zeros(8 * 64, np.uint64)
     L.icpk_debug_read_step_stamps(buf.ctypes.data_as(C.POINTER(C.c_ulonglong)))
     b = buf.reshape(64, 8).astype(np.int64)[:20]
