@@ -928,7 +928,8 @@ static int device_loop_begin(icpk_ctx* ctx, const icpk_params* p, bool throttled
   LoopState* h = ctx->st_host;
   std::memset(h, 0, offsetof(LoopState, trace_R));
   if (throttled) {
-    ctx->progress[0] = ctx->progress[1] = 0;
+    ctx->loop_epoch = (ctx->loop_epoch % 1000000) + 1;  // (<< 10 must fit an int)
+    h->epoch = ctx->loop_epoch;
     h->progress = ctx->progress_dev;
   }
   h->Trot[0] = h->Trot[4] = h->Trot[8] = 1.f;
@@ -1002,14 +1003,19 @@ static int device_loop_finish(icpk_ctx* ctx, const icpk_params* p, float T_out[1
 // stream now and then so that a faulted kernel ends the wait with an error instead of hanging the caller.
 static int wait_loop_progress(icpk_ctx* ctx, int steps, bool* exited) {
   volatile int* pr = ctx->progress;
+  const int e = ctx->loop_epoch;
+  auto look = [&]() -> int {  // 1: the loop has exited, 2: `steps` steps have run, 0: neither yet
+    const int w0 = __atomic_load_n(&pr[0], __ATOMIC_ACQUIRE), w1 = pr[1];
+    if (w1 == ((e << 1) | 1)) return 1;
+    return ((w0 >> 10) == e && (w0 & 1023) >= steps) ? 2 : 0;
+  };
   auto t_query = std::chrono::steady_clock::now() + std::chrono::milliseconds(20);
   for (unsigned spin = 1;; ++spin) {
-    const int k = __atomic_load_n(&pr[0], __ATOMIC_ACQUIRE);
-    if (pr[1]) {
-      *exited = true;
+    const int got = look();
+    if (got) {
+      *exited = got == 1;
       return ICPK_OK;
     }
-    if (k >= steps) return ICPK_OK;
     __builtin_ia32_pause();
     if ((spin & 0x3ff) != 0) continue;
     std::this_thread::yield();
@@ -1019,9 +1025,9 @@ static int wait_loop_progress(icpk_ctx* ctx, int steps, bool* exited) {
     t_query = now + std::chrono::milliseconds(20);
     const hipError_t q = hipStreamQuery(ctx->stream);
     if (q == hipSuccess) {  // drained: the words are final
-      *exited = pr[1] != 0;
-      if (!*exited && __atomic_load_n(&pr[0], __ATOMIC_ACQUIRE) < steps)
-        return fail(ctx, ICPK_E_HIP, "device loop made no progress");
+      const int fin = look();
+      if (!fin) return fail(ctx, ICPK_E_HIP, "device loop made no progress");
+      *exited = fin == 1;
       return ICPK_OK;
     }
     if (q != hipErrorNotReady) return fail(ctx, ICPK_E_HIP, hipGetErrorString(q));

@@ -169,11 +169,13 @@ struct LoopState {
   int steps;                 // loop steps executed (mirrored to *progress)
   long long pairs;           // associations of the latest sweep
   float mse;                 // icp.cpp:622-638 of the latest sweep
-  float pad1;
+  int epoch;                 // tag of this alignment in the progress words (see below)
   // host-visible (pinned, mapped) progress words or nullptr: [0] = loop steps executed, [1] = loop has
   // exited.  With a loop that may exit early (threshold mode) the host enqueues only a couple of
   // iterations ahead of them instead of all max_iterations: every launch after the exit is a no-op that
-  // still costs its dispatch (~3 us each: 100 us for the reference's 16 / 1e-4 setting leaving after 5)
+  // still costs its dispatch (~3 us each: 100 us for the reference's 16 / 1e-4 setting leaving after 5).
+  // Both words carry `epoch` ([0] = epoch << 10 | steps, [1] = epoch << 1 | exited), so that words still
+  // being written by an alignment that was abandoned on an error are never taken for this one's.
   int* progress;
   Rt rt;                     // transform to apply in this iteration
   float Trot[9];             // icp.cpp:227-233

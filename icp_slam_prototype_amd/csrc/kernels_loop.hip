@@ -96,8 +96,10 @@ __device__ __forceinline__ void publish_progress(LoopState* __restrict__ st) {
   st->steps = k;
   int* pr = st->progress;
   if (pr) {
-    __hip_atomic_store(pr + 1, st->done | st->stop_after_transform, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(pr, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const int e = st->epoch;
+    __hip_atomic_store(pr + 1, (e << 1) | ((st->done | st->stop_after_transform) != 0), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(pr, (e << 10) | k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
