@@ -325,6 +325,26 @@ void launch_grid_info(const float* fb, int n, float ppc, int xdiv, GridInfo* g, 
 // q_c -/+ rr, so fl(q_c - rr) <= t_c <= fl(q_c + rr) and, grid_cell being monotone, the
 // target's cell lies in [c0, c1].  (Round 1 used 2^-100 as the absolute term, which is too
 // small below a cloud scale of ~1e-19: sqrt(2^-150) = 2^-75.)
+// ball_trim.  The cube is the box of a ball: a (y, z) row of cells off the query's own row only matters where
+// the ball of the best distance reaches it.  With D = |q - t| in real arithmetic, the chain above gives
+//   D^2 = sum (q_c - t_c)^2 <= (1 + 2^-23)^2 sum fl(q_c - t_c)^2 <= (1 + 2^-22)(1 + 2^-51) S_t
+//       <= r^2 (1 + 2^-20) + 2^-149,   hence   D <= B := r (1 + 2^-19) + 2^-74   (fp32 rounding of B included).
+// A target in cell i of an axis (grid_cell: i <= fl(fl(t - lo) inv_h) < i + 1, unless i is the first or last
+// cell, which also take everything clamped from outside) has  lo + i h - e <= t <= lo + (i + 1) h + e  with
+// e <= 2^-22 n h, so the gap between q and the cell's interval, evaluated in fp32 (errors <= 2^-23 (|q| + |lo|
+// + n h)) and reduced by slop = 2^-20 (|q| + |lo| + n h), is a LOWER bound of |q_c - t_c|; the outer side of
+// an edge cell is unbounded.  For a target of row (iy, iz) therefore
+//   (q_x - t_x)^2 <= B^2 - gap_y^2 - gap_z^2,
+// evaluated with B^2 rounded up and the gaps' squares rounded down: negative -> the row holds nothing that
+// matters; else the x cells come from q_x -/+ (sqrt(.) (1 + 2^-20) + |q_x| 2^-21 + 2^-74) exactly as the
+// cube's do.  Candidates per query on config 2: 32 -> see DESIGN.md.
+__device__ __forceinline__ float axis_gap(float q, float lo, float h, int i, int n, float slop) {
+  const float a = __builtin_fmaf((float)i, h, lo);  // lower edge of cell i
+  const float below = i > 0 ? a - q : 0.f;           // (cell 0 extends to -inf)
+  const float above = i < n - 1 ? q - (a + h) : 0.f;  // (cell n - 1 extends to +inf)
+  return __builtin_fmaxf(__builtin_fmaxf(below, above) - slop, 0.f);
+}
+
 __device__ __forceinline__ void cube_cells(float q, float r, float lo, float inv_h, int n, int& c0, int& c1) {
   const float rr = __builtin_fmaf(r, 1.0f + 0x1p-19f, __builtin_fmaf(__builtin_fabsf(q), 0x1p-21f, 0x1p-74f));
   c0 = grid_cell(q - rr, lo, inv_h, n);
@@ -369,7 +389,7 @@ extern "C" int icpk_debug_clear_grid_stamps() {
 // The sweep of ONE frame pair by workgroup `block` of its launch.  nn_grid_kernel runs it for
 // a single pair (arguments by value); nn_grid_batch_kernel runs blockIdx.y-many independent
 // pairs in lock step (frame-batch mode): same code, same results.
-template <int S, bool EXPAND>
+template <int S, bool EXPAND, bool TRIM>
 __device__ __forceinline__ void nn_grid_body(
     float* __restrict__ qxp, float* __restrict__ qyp, float* __restrict__ qzp, const int nq, float4* __restrict__ qm4,
     const float4* __restrict__ t4, const int* __restrict__ cell_start, const GridInfo* __restrict__ gi,
@@ -444,6 +464,7 @@ __device__ __forceinline__ void nn_grid_body(
   auto scan_cells = [&](int x0, int x1, int y0, int y1, int z0, int z1) {
     const int nyr = y1 - y0 + 1;
     const int nrows = scan ? nyr * (z1 - z0 + 1) : 0;
+
     if (slice == 0) GRID_COUNT(5, nrows);
     for (int r0 = 0; r0 < nrows; r0 += S) {
       const int row = r0 + slice;
@@ -451,9 +472,35 @@ __device__ __forceinline__ void nn_grid_body(
       if (row < nrows) {
         const int rz = row / nyr;
         const int ry = row - rz * nyr;
-        const int base = ((z0 + rz) * g.ny + (y0 + ry)) * g.nx;
-        s0 = cell_start[base + x0];
-        len = cell_start[base + x1 + 1] - s0;
+        const int iy = y0 + ry, iz = z0 + rz;
+        const int base = (iz * g.ny + iy) * g.nx;
+        int xa = x0, xb = x1;
+        // the row's x range trimmed to the BALL of the current best distance (see ball_trim above).  B bounds
+        // the real distance |q - t| of every target that could tie or beat bd; its square must be a normal,
+        // finite float for the arithmetic to mean anything -- else the cube alone.  (Everything is recomputed
+        // per chunk: bd may have improved, and nothing stays live across the candidate loop.)
+        const float B = __builtin_fmaf(bd, 1.0f + 0x1p-19f, 0x1p-74f);
+        if (TRIM && B >= 0x1p-60f && B <= 0x1p60f) {
+          const float B2 = B * B * (1.0f + 0x1p-22f);
+          const float slop_y = (__builtin_fabsf(qy) + (__builtin_fabsf(g.lo[1]) + (float)g.ny * g.h)) * 0x1p-20f;
+          const float slop_z = (__builtin_fabsf(qz) + (__builtin_fabsf(g.lo[2]) + (float)g.nz * g.h)) * 0x1p-20f;
+          const float gy = axis_gap(qy, g.lo[1], g.h, iy, g.ny, slop_y);
+          const float gz = axis_gap(qz, g.lo[2], g.h, iz, g.nz, slop_z);
+          const float G2 = __builtin_fmaf(gy, gy, gz * gz) * (1.0f - 0x1p-22f);
+          const float dx2 = (B2 - G2) * (1.0f + 0x1p-22f);
+          if (dx2 < 0.f) {
+            xb = xa - 1;  // no target of this row can tie or beat the current best
+          } else {
+            const float rrx = __builtin_fmaf(__builtin_sqrtf(dx2), 1.0f + 0x1p-20f,
+                                             __builtin_fmaf(__builtin_fabsf(qx), 0x1p-21f, 0x1p-74f));
+            xa = max(xa, grid_cell(qx - rrx, g.lo[0], g.inv_hx, g.nx));
+            xb = min(xb, grid_cell(qx + rrx, g.lo[0], g.inv_hx, g.nx));
+          }
+        }
+        if (xa <= xb) {
+          s0 = cell_start[base + xa];
+          len = cell_start[base + xb + 1] - s0;
+        }
       }
       GRID_COUNT(6, len);
       // inclusive prefix and total over the S adjacent lanes: DPP moves inside the row of 16
@@ -596,8 +643,11 @@ __device__ __forceinline__ void nn_grid_body(
 
 template <int S, bool EXPAND>
 __global__ __launch_bounds__(ICPK_GRID_BLOCK) void nn_grid_kernel(const GridSweepArgs a) {
-  nn_grid_body<S, EXPAND>(a.qx, a.qy, a.qz, a.nq, a.qm4, a.t4, a.cell_start, a.gi, a.ox, a.oy, a.oz, a.sp_in, a.sp_out,
-                          a.best, a.best_m, a.st, blockIdx.x);
+  // TRIM with 4 lanes per query: the large single clouds (> 262144 queries), where a query's cube holds ~100
+  // candidates and the ball saves a fifth of them (dense 307k pair and config 5: +11 %).  With 8 lanes per
+  // query (config 2) and in the lock-step groups the 6 extra VGPRs cost a wave per SIMD and cancel the gain.
+  nn_grid_body<S, EXPAND, S == 4>(a.qx, a.qy, a.qz, a.nq, a.qm4, a.t4, a.cell_start, a.gi, a.ox, a.oy, a.oz, a.sp_in,
+                                  a.sp_out, a.best, a.best_m, a.st, blockIdx.x);
 }
 
 // frame-batch mode: blockIdx.y = pair.  The pairs of a group differ in size: workgroups beyond
@@ -606,8 +656,8 @@ template <int S, bool EXPAND>
 __global__ __launch_bounds__(ICPK_GRID_BLOCK) void nn_grid_batch_kernel(const GridSweepBatch b) {
   const GridSweepArgs& a = b.p[blockIdx.y];
   if ((long long)blockIdx.x * (64 / S) >= a.nq) return;
-  nn_grid_body<S, EXPAND>(a.qx, a.qy, a.qz, a.nq, a.qm4, a.t4, a.cell_start, a.gi, a.ox, a.oy, a.oz, a.sp_in, a.sp_out,
-                          a.best, a.best_m, a.st, blockIdx.x);
+  nn_grid_body<S, EXPAND, false>(a.qx, a.qy, a.qz, a.nq, a.qm4, a.t4, a.cell_start, a.gi, a.ox, a.oy, a.oz, a.sp_in,
+                                 a.sp_out, a.best, a.best_m, a.st, blockIdx.x);
 }
 
 static inline int grid_blocks(int nq, int slices) { return (nq + (64 / slices) - 1) / (64 / slices); }
