@@ -338,6 +338,20 @@ void launch_grid_info(const float* fb, int n, float ppc, int xdiv, GridInfo* g, 
 // evaluated with B^2 rounded up and the gaps' squares rounded down: negative -> the row holds nothing that
 // matters; else the x cells come from q_x -/+ (sqrt(.) (1 + 2^-20) + |q_x| 2^-21 + 2^-74) exactly as the
 // cube's do.  Candidates per query on config 2: 32 -> see DESIGN.md.
+// pair_dist of nn_device.h from the differences the fp32 filter already holds, one conversion at a time (the
+// same operations, hence the same bits; fewer float64 temporaries alive at the kernel's register peak)
+__device__ __forceinline__ float pair_dist_seq(float dx, float dy, float dz) {
+  double t = (double)dx;
+  double s = t * t;
+  __builtin_amdgcn_sched_barrier(0);
+  t = (double)dy;
+  s = __builtin_fma(t, t, s);
+  __builtin_amdgcn_sched_barrier(0);
+  t = (double)dz;
+  s = __builtin_fma(t, t, s);
+  return __builtin_sqrtf((float)s);
+}
+
 __device__ __forceinline__ float axis_gap(float q, float lo, float h, int i, int n, float slop) {
   const float a = __builtin_fmaf((float)i, h, lo);  // lower edge of cell i
   const float below = i > 0 ? a - q : 0.f;           // (cell 0 extends to -inf)
@@ -386,10 +400,15 @@ extern "C" int icpk_debug_clear_grid_stamps() {
 #endif
 
 #define ICPK_GRID_BLOCK 64  // one wave per workgroup (the row table in LDS relies on it)
+#ifdef ICPK_NO_BALL_TRIM  // (diagnostic builds: the cube alone)
+constexpr bool GRID_BALL_TRIM = false;
+#else
+constexpr bool GRID_BALL_TRIM = true;
+#endif
 // The sweep of ONE frame pair by workgroup `block` of its launch.  nn_grid_kernel runs it for
 // a single pair (arguments by value); nn_grid_batch_kernel runs blockIdx.y-many independent
 // pairs in lock step (frame-batch mode): same code, same results.
-template <int S, bool EXPAND, bool TRIM>
+template <int S, bool EXPAND>
 __device__ __forceinline__ void nn_grid_body(
     float* __restrict__ qxp, float* __restrict__ qyp, float* __restrict__ qzp, const int nq, float4* __restrict__ qm4,
     const float4* __restrict__ t4, const int* __restrict__ cell_start, const GridInfo* __restrict__ gi,
@@ -480,21 +499,23 @@ __device__ __forceinline__ void nn_grid_body(
         // finite float for the arithmetic to mean anything -- else the cube alone.  (Everything is recomputed
         // per chunk: bd may have improved, and nothing stays live across the candidate loop.)
         const float B = __builtin_fmaf(bd, 1.0f + 0x1p-19f, 0x1p-74f);
-        if (TRIM && B >= 0x1p-60f && B <= 0x1p60f) {
+        if (GRID_BALL_TRIM && B >= 0x1p-60f && B <= 0x1p60f) {
           const float B2 = B * B * (1.0f + 0x1p-22f);
-          const float slop_y = (__builtin_fabsf(qy) + (__builtin_fabsf(g.lo[1]) + (float)g.ny * g.h)) * 0x1p-20f;
-          const float slop_z = (__builtin_fabsf(qz) + (__builtin_fabsf(g.lo[2]) + (float)g.nz * g.h)) * 0x1p-20f;
-          const float gy = axis_gap(qy, g.lo[1], g.h, iy, g.ny, slop_y);
-          const float gz = axis_gap(qz, g.lo[2], g.h, iz, g.nz, slop_z);
+          float qx_ = qx, qy_ = qy, qz_ = qz;  // (opaque copies: keep the loop-invariant terms from being hoisted into registers)
+          asm volatile("" : "+v"(qx_), "+v"(qy_), "+v"(qz_));
+          const float slop_y = (__builtin_fabsf(qy_) + (__builtin_fabsf(g.lo[1]) + (float)g.ny * g.h)) * 0x1p-20f;
+          const float slop_z = (__builtin_fabsf(qz_) + (__builtin_fabsf(g.lo[2]) + (float)g.nz * g.h)) * 0x1p-20f;
+          const float gy = axis_gap(qy_, g.lo[1], g.h, iy, g.ny, slop_y);
+          const float gz = axis_gap(qz_, g.lo[2], g.h, iz, g.nz, slop_z);
           const float G2 = __builtin_fmaf(gy, gy, gz * gz) * (1.0f - 0x1p-22f);
           const float dx2 = (B2 - G2) * (1.0f + 0x1p-22f);
           if (dx2 < 0.f) {
             xb = xa - 1;  // no target of this row can tie or beat the current best
           } else {
             const float rrx = __builtin_fmaf(__builtin_sqrtf(dx2), 1.0f + 0x1p-20f,
-                                             __builtin_fmaf(__builtin_fabsf(qx), 0x1p-21f, 0x1p-74f));
-            xa = max(xa, grid_cell(qx - rrx, g.lo[0], g.inv_hx, g.nx));
-            xb = min(xb, grid_cell(qx + rrx, g.lo[0], g.inv_hx, g.nx));
+                                             __builtin_fmaf(__builtin_fabsf(qx_), 0x1p-21f, 0x1p-74f));
+            xa = max(xa, grid_cell(qx_ - rrx, g.lo[0], g.inv_hx, g.nx));
+            xb = min(xb, grid_cell(qx_ + rrx, g.lo[0], g.inv_hx, g.nx));
           }
         }
         if (xa <= xb) {
@@ -552,7 +573,7 @@ __device__ __forceinline__ void nn_grid_body(
           // (the current best itself -- in steady state usually the seed, met again in its cell --
           // cannot improve on itself: skipping it keeps more waves out of the float64 path)
           if (e2 <= T && v0 + k * S < C && __float_as_int(v[k].w) != bj) {
-            const float d = pair_dist(qx, qy, qz, v[k].x, v[k].y, v[k].z);
+            const float d = pair_dist_seq(dx, dy, dz);
             const int jj = __float_as_int(v[k].w);
             const bool up = (d < bd) | ((d == bd) & (jj < bj));
             bd = up ? d : bd;
@@ -643,11 +664,8 @@ __device__ __forceinline__ void nn_grid_body(
 
 template <int S, bool EXPAND>
 __global__ __launch_bounds__(ICPK_GRID_BLOCK) void nn_grid_kernel(const GridSweepArgs a) {
-  // TRIM with 4 lanes per query: the large single clouds (> 262144 queries), where a query's cube holds ~100
-  // candidates and the ball saves a fifth of them (dense 307k pair and config 5: +11 %).  With 8 lanes per
-  // query (config 2) and in the lock-step groups the 6 extra VGPRs cost a wave per SIMD and cancel the gain.
-  nn_grid_body<S, EXPAND, S == 4>(a.qx, a.qy, a.qz, a.nq, a.qm4, a.t4, a.cell_start, a.gi, a.ox, a.oy, a.oz, a.sp_in,
-                                  a.sp_out, a.best, a.best_m, a.st, blockIdx.x);
+  nn_grid_body<S, EXPAND>(a.qx, a.qy, a.qz, a.nq, a.qm4, a.t4, a.cell_start, a.gi, a.ox, a.oy, a.oz, a.sp_in, a.sp_out,
+                          a.best, a.best_m, a.st, blockIdx.x);
 }
 
 // frame-batch mode: blockIdx.y = pair.  The pairs of a group differ in size: workgroups beyond
@@ -656,8 +674,8 @@ template <int S, bool EXPAND>
 __global__ __launch_bounds__(ICPK_GRID_BLOCK) void nn_grid_batch_kernel(const GridSweepBatch b) {
   const GridSweepArgs& a = b.p[blockIdx.y];
   if ((long long)blockIdx.x * (64 / S) >= a.nq) return;
-  nn_grid_body<S, EXPAND, false>(a.qx, a.qy, a.qz, a.nq, a.qm4, a.t4, a.cell_start, a.gi, a.ox, a.oy, a.oz, a.sp_in,
-                                 a.sp_out, a.best, a.best_m, a.st, blockIdx.x);
+  nn_grid_body<S, EXPAND>(a.qx, a.qy, a.qz, a.nq, a.qm4, a.t4, a.cell_start, a.gi, a.ox, a.oy, a.oz, a.sp_in, a.sp_out,
+                          a.best, a.best_m, a.st, blockIdx.x);
 }
 
 static inline int grid_blocks(int nq, int slices) { return (nq + (64 / slices) - 1) / (64 / slices); }
