@@ -1649,6 +1649,7 @@ int align_batch_impl(icpk_ctx* ctx, int32_t n_pairs, const icpk_pair* pairs, con
   };
   GroupRun prev;
   bool have_prev = false;
+  std::vector<icpk_ctx*> unfinished;  // slots whose set-up stopped half-way (see the end of this function)
   for (int gi = 0; gi < ngroups; ++gi) {
     const auto t0 = now();
         GroupRun g;
@@ -1695,7 +1696,10 @@ int align_batch_impl(icpk_ctx* ctx, int32_t n_pairs, const icpk_pair* pairs, con
     std::vector<icpk_ctx*> act;
     std::vector<GridSweepArgs> first;
     for (int k = 0; k < g.count; ++k) {
-      if (g.rc[k] != ICPK_OK) continue;
+      if (g.rc[k] != ICPK_OK) {
+        if (g.rc[k] < 0) unfinished.push_back(ctx->slots[(size_t)g.set * G + k]);
+        continue;
+      }
       act.push_back(ctx->slots[(size_t)g.set * G + k]);
       first.push_back(fargs[k]);
     }
@@ -1717,9 +1721,11 @@ int align_batch_impl(icpk_ctx* ctx, int32_t n_pairs, const icpk_pair* pairs, con
   const auto te0 = now();
   if (have_prev) finish_group(prev);
   const auto te1 = now();
-  // host input buffers were read asynchronously: everything has landed before we return
+  // host input buffers were read asynchronously: everything has landed before we return.  A pair that went
+  // through the loop has: its slot's stream reached `ready_ev` before the group's loop started, and the loop
+  // has been waited for.  Only slots whose set-up FAILED may still have copies in flight.
   ICPK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  for (icpk_ctx* sl : ctx->slots) ICPK_HIP(ctx, hipStreamSynchronize(sl->stream));
+  for (icpk_ctx* sl : unfinished) ICPK_HIP(ctx, hipStreamSynchronize(sl->stream));
   if (trace) std::fprintf(stderr, "icpk batch tail: wait+finish last group %.0f us, stream syncs %.0f us\n", us(te0, te1), us(te1, now()));
   return worst;
 }

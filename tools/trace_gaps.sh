@@ -3,13 +3,13 @@
 # tools/one_align.py): start/end stamps of consecutive dispatches on the alignment's stream.
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/tg
-rocprofv3 --kernel-trace --output-format csv -d /tmp/tg -o t -- python3 $GRAFT_REPO_ROOT/tools/one_align.py --reps 3 > /tmp/tg.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d /tmp/tg -o t -- python3 $GRAFT_REPO_ROOT/tools/one_align.py --reps 3 $ONE_ALIGN_ARGS > /tmp/tg.log 2>&1
 f=$(find /tmp/tg -name '*kernel_trace.csv' | head -n 1)
 python3 - "$f" <<'PY'
 import csv, sys, collections
 rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Timestamp"]))
 def short(n):
-    for k in ("nn_grid_kernel", "assoc_reduce", "loop_step", "copyBuffer", "grid_qslot", "grid_scan_sums", "grid_scan_apply", "grid_qscatter", "fill"):
+    for k in ("nn_grid_batch", "assoc_reduce_batch", "loop_step_batch", "nn_grid_kernel", "assoc_reduce", "loop_step", "copyBuffer", "grid_qslot", "grid_scan_sums", "grid_scan_apply", "grid_qscatter", "fill"):
         if k in n: return k
     return n[:24]
 gaps = collections.defaultdict(list); durs = collections.defaultdict(list)
