@@ -623,6 +623,89 @@ int icpk_host_target_replaced(icpk_ctx* ctx) {
   return ICPK_OK;
 }
 
+// ---- deferred set-up launches (icpk_internal.h) ----
+namespace icpk {
+SetupRecorder*& setup_recorder() {
+  static thread_local SetupRecorder* rec = nullptr;
+  return rec;
+}
+
+// every pair of the group recorded the same steps in the same order?
+static bool same_sequences(const SetupRecorder* recs, int count) {
+  for (int k = 0; k < count; ++k) {
+    if (recs[k].overflow || recs[k].n != recs[0].n) return false;
+    for (int j = 0; j < recs[0].n; ++j)
+      if (recs[k].calls[j].kind != recs[0].calls[j].kind) return false;
+  }
+  return true;
+}
+
+bool flush_setup_batches(const SetupRecorder* recs, int count, hipStream_t s) {
+  if (count <= 0) return true;
+  if (count > BATCH_MAX || !same_sequences(recs, count)) return false;
+  for (int j = 0; j < recs[0].n; ++j) {
+#define ICPK_STEP(KIND, FIELD, TYPE, LAUNCH)                        \
+  case KIND: {                                                      \
+    SetupBatchOf<TYPE> b;                                           \
+    for (int k = 0; k < count; ++k) b.p[k] = recs[k].calls[j].FIELD; \
+    LAUNCH(b, count, s);                                            \
+    break;                                                          \
+  }
+    switch (recs[0].calls[j].kind) {
+      ICPK_STEP(SK_INGEST, ingest, IngestArgs, launch_ingest_batch)
+      ICPK_STEP(SK_LOOP_INIT, loop_init, LoopInitArgs, launch_loop_init_batch)
+      ICPK_STEP(SK_BOUNDS, bounds, BoundsArgs, launch_grid_bounds_batch)
+      ICPK_STEP(SK_INFO, info, InfoArgs, launch_grid_info_batch)
+      ICPK_STEP(SK_QSLOT, qslot, QslotArgs, launch_grid_qslot_batch)
+      ICPK_STEP(SK_SCAN, scan, ScanArgs, launch_grid_scan_batch)
+      ICPK_STEP(SK_TSCATTER, tscatter, TscatterArgs, launch_grid_tscatter_batch)
+      ICPK_STEP(SK_QSCATTER, qscatter, QscatterArgs, launch_grid_qscatter_batch)
+      default: return false;
+    }
+#undef ICPK_STEP
+  }
+  return true;
+}
+
+// one pair's recorded steps, launched one by one (the sequences of a group differed)
+void replay_setup(const SetupRecorder& rec, hipStream_t s) {
+  SetupRecorder* const saved = setup_recorder();
+  setup_recorder() = nullptr;
+  for (int j = 0; j < rec.n; ++j) {
+    const SetupCall& c = rec.calls[j];
+    switch (c.kind) {
+      case SK_INGEST: {
+        const IngestArgs& a = c.ingest;
+        launch_ingest_cloud(a.x, a.y, a.z, a.n, a.n_pad, a.pad, a.d1, a.cap1, a.d2, a.cap2, s);
+        break;
+      }
+      case SK_LOOP_INIT: launch_loop_init(c.loop_init, s); break;
+      case SK_BOUNDS: launch_grid_bounds(c.bounds.x, c.bounds.y, c.bounds.z, c.bounds.n, c.bounds.fb, s); break;
+      case SK_INFO: launch_grid_info(c.info.fb, c.info.n, c.info.ppc, c.info.xdiv, c.info.g, s); break;
+      case SK_QSLOT: {
+        const QslotArgs& a = c.qslot;
+        launch_grid_qslot(a.x, a.y, a.z, a.n, a.gi, a.count, a.cell, a.slot, a.coarse, s);
+        break;
+      }
+      case SK_SCAN: launch_grid_scan(c.scan.count, c.scan.out, c.scan.bsum, c.scan.g, c.scan.coarse, s); break;
+      case SK_TSCATTER: {
+        const TscatterArgs& a = c.tscatter;
+        launch_grid_tscatter(a.x, a.y, a.z, a.tcell, a.tslot, a.cell_start, a.n, a.t4, a.o4, s);
+        break;
+      }
+      case SK_QSCATTER: {
+        const QscatterArgs& a = c.qscatter;
+        launch_grid_qscatter(a.qcell, a.qslot, a.qstart, a.n, a.qperm, a.qx, a.qy, a.qz, a.ox, a.oy, a.oz, a.qm4, a.sp,
+                             a.seed_m, s);
+        break;
+      }
+      default: break;
+    }
+  }
+  setup_recorder() = saved;
+}
+}  // namespace icpk
+
 extern "C" {
 
 const char* icpk_version(void) { return ICPK_VERSION_STRING; }
@@ -714,6 +797,7 @@ int icpk_create(icpk_ctx** out, int device_id) {
     const int v = std::atoi(e);
     if (v >= 1 && v <= 16) ctx->batch_threads = v;
   }
+  if (const char* e = std::getenv("ICPK_BATCH_SETUP")) ctx->batch_setup = std::atoi(e) != 0;
   if (const char* e = std::getenv("ICPK_LOOP_AHEAD")) {  // 0: enqueue every iteration up front
     const int v = std::atoi(e);
     if (v >= 0 && v <= LOOP_MAX_ITER) ctx->loop_ahead = v;
@@ -729,7 +813,9 @@ void icpk_destroy(icpk_ctx* ctx) {
   icpk_comm_release(ctx);
   for (icpk_ctx* sl : ctx->slots) icpk_destroy(sl);
   ctx->slots.clear();
-  for (hipEvent_t e : {ctx->ready_ev, ctx->group_ev[0], ctx->group_ev[1]})
+  for (hipStream_t st : {ctx->setup_stream[0], ctx->setup_stream[1]})
+    if (st) (void)hipStreamDestroy(st);
+  for (hipEvent_t e : {ctx->ready_ev, ctx->group_ev[0], ctx->group_ev[1], ctx->setup_ev[0], ctx->setup_ev[1]})
     if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : ctx->events) (void)hipEventDestroy(e);
   void* dev[] = {ctx->qcount, ctx->qstart, ctx->scan_bsum, ctx->qm4, ctx->sp_in, ctx->sp_out, ctx->grid_info, ctx->grid_bounds, ctx->cell_start, ctx->t4, ctx->o4, ctx->best_m, ctx->seed_m, ctx->st_dev, ctx->sorted.base, ctx->tkeys, ctx->tperm, ctx->qperm, ctx->bounds, ctx->sort_keys, ctx->sort_vals, ctx->sort_temp,
@@ -925,23 +1011,22 @@ static int loop_nsum(const icpk_params* p) {
 
 // initial LoopState -> device (on ctx->stream), stop flags armed
 static int device_loop_begin(icpk_ctx* ctx, const icpk_params* p, bool throttled = false) {
-  LoopState* h = ctx->st_host;
-  std::memset(h, 0, offsetof(LoopState, trace_R));
+  LoopInitArgs a{};
+  a.st = ctx->st_dev;
   if (throttled) {
     ctx->loop_epoch = (ctx->loop_epoch % 1000000) + 1;  // (<< 10 must fit an int)
-    h->epoch = ctx->loop_epoch;
-    h->progress = ctx->progress_dev;
+    a.epoch = ctx->loop_epoch;
+    a.progress = ctx->progress_dev;
   }
-  h->Trot[0] = h->Trot[4] = h->Trot[8] = 1.f;
-  h->Tk[0] = h->Tk[5] = h->Tk[10] = 1.0;
-  h->max_iterations = p->max_iterations;
-  h->min_pairs = p->min_pairs;
-  h->solve = p->solve;
-  h->fixed_iterations = p->fixed_iterations;
-  h->threshold = p->threshold;
-  std::memcpy(h->last_rotation, p->last_rotation, sizeof(h->last_rotation));
-  std::memcpy(h->last_translation, p->last_translation, sizeof(h->last_translation));
-  ICPK_HIP(ctx, hipMemcpyAsync(ctx->st_dev, h, offsetof(LoopState, trace_R), hipMemcpyHostToDevice, ctx->stream));
+  a.max_iterations = p->max_iterations;
+  a.min_pairs = p->min_pairs;
+  a.solve = p->solve;
+  a.fixed_iterations = p->fixed_iterations;
+  a.threshold = p->threshold;
+  std::memcpy(a.last_rotation, p->last_rotation, sizeof(a.last_rotation));
+  std::memcpy(a.last_translation, p->last_translation, sizeof(a.last_translation));
+  launch_loop_init(a, ctx->stream);  // (values travel in the kernel arguments: no staging copy)
+  ICPK_HIP(ctx, hipGetLastError());
   const int nsum = loop_nsum(p);
   ctx->loop_nact = nsum == NSUM_REF ? NSUM_REF : NSUM;
   // the stop flags are only meaningful while this alignment is being enqueued
@@ -1489,7 +1574,8 @@ int slot_setup_phase2(icpk_ctx* sl, const icpk_params* p, GridSweepArgs& first) 
   first = grid_sweep_args(sl, a, bx);
   after_grid_sweep(sl);
   sl->best_of_sweep.push_back(sl->best);
-  ICPK_HIP(sl, hipEventRecord(sl->ready_ev, sl->stream));
+  // (while the launches are being recorded the group's set-up event, recorded after the flush, takes its place)
+  if (!setup_recorder()) ICPK_HIP(sl, hipEventRecord(sl->ready_ev, sl->stream));
   return ICPK_OK;
 }
 
@@ -1513,16 +1599,22 @@ ReduceArgs slot_reduce_args(const icpk_ctx* sl) {
 
 // the whole loop of a group on the parent's stream, then the read-back of every loop state
 int enqueue_group_loop(icpk_ctx* ctx, const icpk_params* p, const std::vector<icpk_ctx*>& act,
-                       const std::vector<GridSweepArgs>& first, int set) {
+                       const std::vector<GridSweepArgs>& first, int set, const std::vector<bool>& own_event) {
   const int n = (int)act.size();
   if (n == 0) return ICPK_OK;
   const int nsum = loop_nsum(p);
   const int nact = nsum == NSUM_REF ? NSUM_REF : NSUM;
   long long nq_total = 0;
-  for (icpk_ctx* sl : act) {
-    ICPK_HIP(ctx, hipStreamWaitEvent(ctx->stream, sl->ready_ev, 0));
+  bool group_event = false;
+  for (int k = 0; k < n; ++k) {
+    icpk_ctx* sl = act[k];
+    if (own_event[k])
+      ICPK_HIP(ctx, hipStreamWaitEvent(ctx->stream, sl->ready_ev, 0));
+    else
+      group_event = true;  // set up by the group's batched launches
     nq_total += sl->src.n;
   }
+  if (group_event) ICPK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->setup_ev[set], 0));
   // lanes per query: a single pair is latency-bound and wants 8; a group that fills the GPU
   // several times over is issue-bound and does better with fewer, longer lanes (measured on
   // 8 config-2 pairs: 43.4k iter/s with 8, 50.6k with 4, 48.2k with 2)
@@ -1678,10 +1770,44 @@ int align_batch_impl(icpk_ctx* ctx, int32_t n_pairs, const icpk_pair* pairs, con
       if (r != ICPK_OK) device_loop_disarm(sl);
       g.rc[k] = r;
     };
+    // Device-resident pairs: the set-up launches of the whole group are RECORDED (icpk_internal.h, SetupRecorder)
+    // and issued as one launch per step on the set's set-up stream -- 13 launches instead of 13 per pair.
+    std::vector<bool> recorded(g.count, false);
+    const bool batched = kind == hipMemcpyDeviceToDevice && ctx->batch_setup != 0;
     // (host buffers: one thread -- concurrent host-to-device copies from several threads stall for
     // ~9 ms at random on this runtime, tools/one_align.py --batch under ICPK_BATCH_TRACE)
-    const int nthreads = kind == hipMemcpyHostToDevice ? 1 : (g.count < ctx->batch_threads ? g.count : ctx->batch_threads);
-    if (nthreads <= 1) {
+    const int nthreads = batched || kind == hipMemcpyHostToDevice ? 1 : (g.count < ctx->batch_threads ? g.count : ctx->batch_threads);
+    if (batched) {
+      if (!ctx->setup_stream[g.set]) {
+        ICPK_HIP(ctx, hipStreamCreateWithFlags(&ctx->setup_stream[g.set], hipStreamNonBlocking));
+        ICPK_HIP(ctx, hipEventCreateWithFlags(&ctx->setup_ev[g.set], hipEventDisableTiming));
+      }
+      const hipStream_t ss = ctx->setup_stream[g.set];
+      std::vector<SetupRecorder> recs(g.count);
+      for (int k = 0; k < g.count; ++k) {
+        icpk_ctx* sl = ctx->slots[(size_t)g.set * G + k];
+        if (pairs[g.first + k].ns <= 0) {  // goes down the single-pair path at once: nothing to defer
+          setup_one(k);
+          continue;
+        }
+        const hipStream_t own = sl->stream;
+        sl->stream = ss;  // whatever is not recorded (first-use clears) must precede the flushed launches
+        setup_recorder() = &recs[k];
+        setup_one(k);
+        setup_recorder() = nullptr;
+        sl->stream = own;
+        recorded[k] = g.rc[k] == ICPK_OK;
+      }
+      std::vector<SetupRecorder> ok;
+      for (int k = 0; k < g.count; ++k)
+        if (recorded[k]) ok.push_back(recs[k]);
+      if (!ok.empty()) {
+        if (!flush_setup_batches(ok.data(), (int)ok.size(), ss))
+          for (const SetupRecorder& r : ok) replay_setup(r, ss);
+        ICPK_HIP(ctx, hipGetLastError());
+        ICPK_HIP(ctx, hipEventRecord(ctx->setup_ev[g.set], ss));
+      }
+    } else if (nthreads <= 1) {
       for (int k = 0; k < g.count; ++k) setup_one(k);
     } else {
       std::vector<std::thread> pool;
@@ -1695,6 +1821,7 @@ int align_batch_impl(icpk_ctx* ctx, int32_t n_pairs, const icpk_pair* pairs, con
     const auto t1 = now();
     std::vector<icpk_ctx*> act;
     std::vector<GridSweepArgs> first;
+    std::vector<bool> own_event;
     for (int k = 0; k < g.count; ++k) {
       if (g.rc[k] != ICPK_OK) {
         if (g.rc[k] < 0) unfinished.push_back(ctx->slots[(size_t)g.set * G + k]);
@@ -1702,9 +1829,10 @@ int align_batch_impl(icpk_ctx* ctx, int32_t n_pairs, const icpk_pair* pairs, con
       }
       act.push_back(ctx->slots[(size_t)g.set * G + k]);
       first.push_back(fargs[k]);
+      own_event.push_back(!recorded[k]);
     }
     const auto t2 = now();
-    rc = enqueue_group_loop(ctx, p, act, first, g.set);
+    rc = enqueue_group_loop(ctx, p, act, first, g.set, own_event);
     if (rc) {  // enqueue failed: nothing of this group can be trusted
       for (icpk_ctx* sl : act) device_loop_disarm(sl);
       (void)hipStreamSynchronize(ctx->stream);

@@ -109,6 +109,9 @@ struct icpk_ctx {
   std::vector<icpk_ctx*> slots;
   hipEvent_t ready_ev = nullptr;       // slot: set-up of the current pair is enqueued up to here
   hipEvent_t group_ev[2] = {nullptr, nullptr};  // parent: the lock-step loop of a slot set has finished
+  hipStream_t setup_stream[2] = {nullptr, nullptr};  // parent: the batched set-up launches of a slot set (created on first use)
+  hipEvent_t setup_ev[2] = {nullptr, nullptr};       // ... and their completion
+  int batch_setup = 1;                               // 0 (ICPK_BATCH_SETUP=0): per-pair set-up launches on the slots' own streams
   int batch_group = 16;                // pairs advancing in lock step (ICPK_BATCH_GROUP, <= BATCH_MAX)
   int batch_threads = 4;               // host threads sharing a group's set-up calls (ICPK_BATCH_THREADS)
   std::vector<nn_key_t*> best_of_sweep;  // device loop: which buffer each enqueued sweep wrote

@@ -281,4 +281,106 @@ void launch_assoc_split(const nn_key_t* best, int nq, float max_dist, int* block
 void launch_depth_filter(const uint16_t* in, uint16_t* out, int rows, int cols, int min_d, int max_d, int ax, int ay,
                          int morph, hipStream_t s);
 
+
+// ---- deferred set-up launches of the frame-batch mode ------------------------------------------------
+// A lock-step group's pairs go through the SAME sequence of small set-up kernels (ingest x 2, loop-state
+// init, bounds, grid info, 2 x (cell slots, scan sums, scan), target scatter, query scatter): 13 launches per
+// pair on its own stream, which for 8 pairs is 0.26 ms that nothing hides when the group is the only one
+// (config 4 at 8 GPUs).  While a SetupRecorder is installed in the calling thread the launchers below
+// RECORD their arguments instead of launching; flush_setup_batches() then issues ONE launch per step for
+// all pairs (blockIdx.y / blockIdx.x = pair, arguments by value), or, should the pairs' sequences differ,
+// replays them one by one.  Same kernels' bodies: same bits.
+struct IngestArgs {
+  const float *x, *y, *z;
+  int n, n_pad;
+  float pad;
+  int cap1;
+  float* d1;
+  float* d2;
+  int cap2;
+  int pad0;
+};
+struct LoopInitArgs {
+  LoopState* st;
+  int* progress;
+  int max_iterations, min_pairs, solve, fixed_iterations;
+  float threshold;
+  int epoch;
+  float last_rotation[9], last_translation[3];
+};
+struct BoundsArgs {
+  const float *x, *y, *z;
+  float* fb;
+  int n, nparts;
+};
+struct InfoArgs {
+  const float* fb;
+  GridInfo* g;
+  int nparts, n;
+  float ppc;
+  int xdiv;
+};
+struct QslotArgs {
+  const float *x, *y, *z;
+  const GridInfo* gi;
+  int *count, *cell, *slot;
+  int n, coarse;
+};
+struct ScanArgs {
+  int *count, *out, *bsum;
+  const GridInfo* g;
+  int coarse, pad0;
+};
+struct TscatterArgs {
+  const float *x, *y, *z;
+  const int *tcell, *tslot, *cell_start;
+  float4 *t4, *o4;
+  int n, pad0;
+};
+struct QscatterArgs {
+  const int *qcell, *qslot, *qstart;
+  int* qperm;
+  const float *qx, *qy, *qz, *ox, *oy, *oz;
+  float4 *qm4, *sp;
+  nn_key_t* seed_m;
+  int n, pad0;
+};
+enum SetupKind : int { SK_INGEST, SK_LOOP_INIT, SK_BOUNDS, SK_INFO, SK_QSLOT, SK_SCAN, SK_TSCATTER, SK_QSCATTER };
+struct SetupCall {
+  int kind;
+  union {
+    IngestArgs ingest;
+    LoopInitArgs loop_init;
+    BoundsArgs bounds;
+    InfoArgs info;
+    QslotArgs qslot;
+    ScanArgs scan;
+    TscatterArgs tscatter;
+    QscatterArgs qscatter;
+  };
+};
+struct SetupRecorder {
+  SetupCall calls[24];
+  int n = 0;
+  bool overflow = false;
+};
+SetupRecorder*& setup_recorder();  // of the calling thread; nullptr: launch at once
+template <typename A>
+struct SetupBatchOf {
+  A p[BATCH_MAX];
+};
+void launch_loop_init(const LoopInitArgs& a, hipStream_t s);
+// one launch per recorded step for `count` pairs, in recording order; returns false if the sequences differ
+// (nothing launched then: replay them with replay_setup)
+bool flush_setup_batches(const SetupRecorder* recs, int count, hipStream_t s);
+void replay_setup(const SetupRecorder& rec, hipStream_t s);
+void launch_ingest_batch(const SetupBatchOf<IngestArgs>& b, int count, hipStream_t s);
+void launch_loop_init_batch(const SetupBatchOf<LoopInitArgs>& b, int count, hipStream_t s);
+void launch_grid_bounds_batch(const SetupBatchOf<BoundsArgs>& b, int count, hipStream_t s);
+void launch_grid_info_batch(const SetupBatchOf<InfoArgs>& b, int count, hipStream_t s);
+void launch_grid_qslot_batch(const SetupBatchOf<QslotArgs>& b, int count, hipStream_t s);
+void launch_grid_scan_batch(const SetupBatchOf<ScanArgs>& b, int count, hipStream_t s);
+void launch_grid_tscatter_batch(const SetupBatchOf<TscatterArgs>& b, int count, hipStream_t s);
+void launch_grid_qscatter_batch(const SetupBatchOf<QscatterArgs>& b, int count, hipStream_t s);
+
 }  // namespace icpk

@@ -25,17 +25,15 @@ namespace icpk {
 // ---- set-up ---------------------------------------------------------------------------
 // bounds over the FINITE coordinates only (a non-finite target can never be selected: its
 // distance is inf/NaN, and the seed of such a query is element 0, the lowest index)
-__global__ __launch_bounds__(1024) void grid_bounds_kernel(const float* __restrict__ x, const float* __restrict__ y,
-                                                           const float* __restrict__ z, int n,
-                                                           float* __restrict__ fb) {
+__device__ __forceinline__ void grid_bounds_body(const BoundsArgs& a, const int part) {
   __shared__ float red[6][16];
-  const float* p[3] = {x, y, z};
+  const float* p[3] = {a.x, a.y, a.z};
   float lo[3], hi[3];
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     lo[c] = __builtin_inff();
     hi[c] = -__builtin_inff();
-    for (int i = blockIdx.x * 1024 + threadIdx.x; i < n; i += gridDim.x * 1024) {
+    for (int i = part * 1024 + threadIdx.x; i < a.n; i += a.nparts * 1024) {
       const float v = p[c][i];
       if (v - v == 0.f) {
         lo[c] = __builtin_fminf(lo[c], v);
@@ -57,8 +55,14 @@ __global__ __launch_bounds__(1024) void grid_bounds_kernel(const float* __restri
     float v = red[threadIdx.x][0];
     for (int k = 1; k < 16; ++k)
       v = threadIdx.x < 3 ? __builtin_fminf(v, red[threadIdx.x][k]) : __builtin_fmaxf(v, red[threadIdx.x][k]);
-    fb[blockIdx.x * 6 + threadIdx.x] = v;  // one partial box per block; grid_info_kernel merges them
+    a.fb[part * 6 + threadIdx.x] = v;  // one partial box per block; grid_info_kernel merges them
   }
+}
+__global__ __launch_bounds__(1024) void grid_bounds_kernel(const BoundsArgs a) { grid_bounds_body(a, blockIdx.x); }
+// frame-batch set-up kernels: blockIdx.y = pair of the group; workgroups beyond a pair's own count leave at once
+__global__ __launch_bounds__(1024) void grid_bounds_batch_kernel(const SetupBatchOf<BoundsArgs> b) {
+  const BoundsArgs& a = b.p[blockIdx.y];
+  if ((int)blockIdx.x < a.nparts) grid_bounds_body(a, blockIdx.x);
 }
 
 // cell edge: about `ppc` targets per occupied cell if the cloud is a surface whose area is
@@ -67,8 +71,8 @@ __global__ __launch_bounds__(1024) void grid_bounds_kernel(const float* __restri
 // Cells are `xdiv` times finer along x, the axis the sorted order runs along: a query's cube
 // costs one contiguous range per (y, z) row whatever the x resolution, so finer x cells trim
 // the ranges to the cube (fewer candidates outside it) at no extra look-up.
-__global__ void grid_info_kernel(const float* __restrict__ fbp, int nparts, int n, float ppc, int xdiv,
-                                 GridInfo* __restrict__ g) {
+__device__ __forceinline__ void grid_info_body(const float* __restrict__ fbp, int nparts, int n, float ppc, int xdiv,
+                                               GridInfo* __restrict__ g) {
   // one wave: lane l merges the partial boxes l, l + 64, ...; xor butterfly; lane 0 goes on
   float fb[6];
 #pragma unroll
@@ -124,6 +128,12 @@ __global__ void grid_info_kernel(const float* __restrict__ fbp, int nparts, int 
   g->ncells_q = g->nxq * ny * nz;
 }
 
+__global__ void grid_info_kernel(const InfoArgs a) { grid_info_body(a.fb, a.nparts, a.n, a.ppc, a.xdiv, a.g); }
+__global__ void grid_info_batch_kernel(const SetupBatchOf<InfoArgs> b) {
+  const InfoArgs& a = b.p[blockIdx.x];
+  grid_info_body(a.fb, a.nparts, a.n, a.ppc, a.xdiv, a.g);
+}
+
 // The ONE mapping coordinate -> cell index along an axis, used for targets and for the
 // corners of a query's cube alike.  Every step is monotone non-decreasing in v (float
 // subtraction, multiplication by a positive constant, clamp, truncation of a non-negative
@@ -138,41 +148,36 @@ __device__ __forceinline__ int grid_cell(float v, float lo, float inv_h, int n) 
 // alignment): slot within the cell by atomics -- the order inside a cell may be whatever the
 // atomics make it: target candidates are merged lexicographically, and the query order only
 // matters for locality (results are scattered back by original index).
-__global__ void grid_qslot_kernel(const float* __restrict__ x, const float* __restrict__ y,
-                                  const float* __restrict__ z, int n, const GridInfo* __restrict__ gi,
-                                  int* __restrict__ count, int* __restrict__ qcell, int* __restrict__ qslot,
-                                  int coarse) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const GridInfo g = *gi;
-  const int cx = grid_cell(x[i], g.lo[0], g.inv_hx, g.nx);
-  const int cy = grid_cell(y[i], g.lo[1], g.inv_h, g.ny);
-  const int cz = grid_cell(z[i], g.lo[2], g.inv_h, g.nz);
-  const int c = coarse ? (cz * g.ny + cy) * g.nxq + cx / g.xdiv : (cz * g.ny + cy) * g.nx + cx;
-  qcell[i] = c;
-  qslot[i] = atomicAdd(&count[c], 1);
+__device__ __forceinline__ void grid_qslot_body(const QslotArgs& a, const int block) {
+  const int i = block * blockDim.x + threadIdx.x;
+  if (i >= a.n) return;
+  const GridInfo g = *a.gi;
+  const int cx = grid_cell(a.x[i], g.lo[0], g.inv_hx, g.nx);
+  const int cy = grid_cell(a.y[i], g.lo[1], g.inv_h, g.ny);
+  const int cz = grid_cell(a.z[i], g.lo[2], g.inv_h, g.nz);
+  const int c = a.coarse ? (cz * g.ny + cy) * g.nxq + cx / g.xdiv : (cz * g.ny + cy) * g.nx + cx;
+  a.cell[i] = c;
+  a.slot[i] = atomicAdd(&a.count[c], 1);
 }
+__global__ void grid_qslot_kernel(const QslotArgs a) { grid_qslot_body(a, blockIdx.x); }
+__global__ void grid_qslot_batch_kernel(const SetupBatchOf<QslotArgs> b) { grid_qslot_body(b.p[blockIdx.y], blockIdx.x); }
 
 // qm4 != nullptr: the first sweep of an alignment without seeds -- the queries in scan order (x, y, z, index),
 // the reference's literal seed (element 0, icp.cpp:572) as a point and as a key, written here instead of by
 // a zero fill and grid_query_points_kernel afterwards (two launches less per alignment)
-__global__ void grid_qscatter_kernel(const int* __restrict__ qcell, const int* __restrict__ qslot,
-                                     const int* __restrict__ qstart, int n, int* __restrict__ qperm,
-                                     const float* __restrict__ qx, const float* __restrict__ qy,
-                                     const float* __restrict__ qz, const float* __restrict__ ox,
-                                     const float* __restrict__ oy, const float* __restrict__ oz,
-                                     float4* __restrict__ qm4, float4* __restrict__ sp,
-                                     nn_key_t* __restrict__ seed_m) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const int ip = qstart[qcell[i]] + qslot[i];
-  qperm[ip] = i;
-  if (qm4) {
-    qm4[ip] = make_float4(qx[i], qy[i], qz[i], __int_as_float(i));
-    sp[ip] = make_float4(ox[0], oy[0], oz[0], __int_as_float(0));
-    seed_m[ip] = 0ull;
+__device__ __forceinline__ void grid_qscatter_body(const QscatterArgs& a, const int block) {
+  const int i = block * blockDim.x + threadIdx.x;
+  if (i >= a.n) return;
+  const int ip = a.qstart[a.qcell[i]] + a.qslot[i];
+  a.qperm[ip] = i;
+  if (a.qm4) {
+    a.qm4[ip] = make_float4(a.qx[i], a.qy[i], a.qz[i], __int_as_float(i));
+    a.sp[ip] = make_float4(a.ox[0], a.oy[0], a.oz[0], __int_as_float(0));
+    a.seed_m[ip] = 0ull;
   }
 }
+__global__ void grid_qscatter_kernel(const QscatterArgs a) { grid_qscatter_body(a, blockIdx.x); }
+__global__ void grid_qscatter_batch_kernel(const SetupBatchOf<QscatterArgs> b) { grid_qscatter_body(b.p[blockIdx.y], blockIdx.x); }
 
 // ---- device-sized exclusive scan of the cell counts ----------------------------------------
 // The number of cells lives in GridInfo ON THE DEVICE; these kernels read it there, so the whole
@@ -201,43 +206,44 @@ __device__ __forceinline__ int block_sum_256(int v, int* sh) {  // sum over the 
   return t;
 }
 
-__global__ __launch_bounds__(256) void grid_scan_sums_kernel(const int* __restrict__ in,
-                                                             const GridInfo* __restrict__ gi,
-                                                             int* __restrict__ bsum, int coarse) {
+__device__ __forceinline__ void grid_scan_sums_body(const ScanArgs& a, const int block) {
   __shared__ int sh[4];
-  const int n = grid_table_size(gi, coarse);
-  const int base = blockIdx.x * GSCAN_TILE;
+  const int n = grid_table_size(a.g, a.coarse);
+  const int base = block * GSCAN_TILE;
   if (base >= n) return;
   int v = 0;
 #pragma unroll
   for (int k = 0; k < GSCAN_ITEMS; ++k) {
     const int i = base + k * 256 + threadIdx.x;
-    v += i < n ? in[i] : 0;
+    v += i < n ? a.count[i] : 0;
   }
   const int t = block_sum_256(v, sh);
-  if (threadIdx.x == 0) bsum[blockIdx.x] = t;
+  if (threadIdx.x == 0) a.bsum[block] = t;
+}
+__global__ __launch_bounds__(256) void grid_scan_sums_kernel(const ScanArgs a) { grid_scan_sums_body(a, blockIdx.x); }
+__global__ __launch_bounds__(256) void grid_scan_sums_batch_kernel(const SetupBatchOf<ScanArgs> b) {
+  grid_scan_sums_body(b.p[blockIdx.y], blockIdx.x);
 }
 
-__global__ __launch_bounds__(256) void grid_scan_apply_kernel(int* __restrict__ in, const GridInfo* __restrict__ gi,
-                                                              const int* __restrict__ bsum, int* __restrict__ out,
-                                                              int coarse) {
+__device__ __forceinline__ void grid_scan_apply_body(const ScanArgs& a, const int block) {
   __shared__ int wtot[4];
   __shared__ int sh[4];
-  const int n = grid_table_size(gi, coarse);
-  const int base = blockIdx.x * GSCAN_TILE;
+  int* __restrict__ in = a.count;
+  const int n = grid_table_size(a.g, a.coarse);
+  const int base = block * GSCAN_TILE;
   if (base >= n) return;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   // this block's offset: the sums of the blocks before it
   int before = 0;
-  for (int b = t; b < (int)blockIdx.x; b += 256) before += bsum[b];
+  for (int b = t; b < block; b += 256) before += a.bsum[b];
   const int boff = block_sum_256(before, sh);
   // lane t owns the 8 consecutive counts base + 8 t .. base + 8 t + 7
-  int a[GSCAN_ITEMS], s = 0;
+  int c[GSCAN_ITEMS], s = 0;
 #pragma unroll
   for (int k = 0; k < GSCAN_ITEMS; ++k) {
     const int i = base + GSCAN_ITEMS * t + k;
-    a[k] = i < n ? in[i] : 0;
-    s += a[k];
+    c[k] = i < n ? in[i] : 0;
+    s += c[k];
   }
   int inc = s;
 #pragma unroll
@@ -253,52 +259,95 @@ __global__ __launch_bounds__(256) void grid_scan_apply_kernel(int* __restrict__ 
   for (int k = 0; k < GSCAN_ITEMS; ++k) {
     const int i = base + GSCAN_ITEMS * t + k;
     if (i < n) {
-      out[i] = run;
+      a.out[i] = run;
       in[i] = 0;  // the table is handed back all zero
     }
-    run += a[k];
+    run += c[k];
   }
+}
+__global__ __launch_bounds__(256) void grid_scan_apply_kernel(const ScanArgs a) { grid_scan_apply_body(a, blockIdx.x); }
+__global__ __launch_bounds__(256) void grid_scan_apply_batch_kernel(const SetupBatchOf<ScanArgs> b) {
+  grid_scan_apply_body(b.p[blockIdx.y], blockIdx.x);
 }
 
 // coarse = 1: the table of the query order (ncells_q entries), else the targets' (ncells).
 // out[i] = sum of count[0 .. i) for i in [0, size]; count[] is zero afterwards; bsum: GRID_SCAN_BLOCKS ints
+#define ICPK_RECORD(KIND, FIELD, VALUE)           \
+  if (SetupRecorder* r__ = setup_recorder()) {    \
+    if (r__->n < 24) {                            \
+      r__->calls[r__->n].kind = KIND;             \
+      r__->calls[r__->n++].FIELD = VALUE;         \
+    } else {                                      \
+      r__->overflow = true;                       \
+    }                                             \
+    return;                                       \
+  }
+
 void launch_grid_scan(int* count, int* out, int* bsum, const GridInfo* g, int coarse, hipStream_t s) {
-  hipLaunchKernelGGL(grid_scan_sums_kernel, dim3(GSCAN_MAX_BLOCKS), dim3(256), 0, s, count, g, bsum, coarse);
-  hipLaunchKernelGGL(grid_scan_apply_kernel, dim3(GSCAN_MAX_BLOCKS), dim3(256), 0, s, count, g, bsum, out, coarse);
+  const ScanArgs a{count, out, bsum, g, coarse, 0};
+  ICPK_RECORD(SK_SCAN, scan, a)
+  hipLaunchKernelGGL(grid_scan_sums_kernel, dim3(GSCAN_MAX_BLOCKS), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(grid_scan_apply_kernel, dim3(GSCAN_MAX_BLOCKS), dim3(256), 0, s, a);
+}
+void launch_grid_scan_batch(const SetupBatchOf<ScanArgs>& b, int count, hipStream_t s) {
+  if (count <= 0) return;
+  hipLaunchKernelGGL(grid_scan_sums_batch_kernel, dim3(GSCAN_MAX_BLOCKS, count), dim3(256), 0, s, b);
+  hipLaunchKernelGGL(grid_scan_apply_batch_kernel, dim3(GSCAN_MAX_BLOCKS, count), dim3(256), 0, s, b);
 }
 
 // targets into the AoS copy (x, y, z, original index), one 16-byte load per candidate -- and, in the
 // caller's order, into o4 (x, y, z, 0): K2 fetches a matched point with one load instead of three
-__global__ void grid_tscatter_kernel(const float* __restrict__ x, const float* __restrict__ y,
-                                     const float* __restrict__ z, const int* __restrict__ tcell,
-                                     const int* __restrict__ tslot, const int* __restrict__ cell_start, int n,
-                                     float4* __restrict__ t4, float4* __restrict__ o4) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const float px = x[i], py = y[i], pz = z[i];
-  t4[cell_start[tcell[i]] + tslot[i]] = make_float4(px, py, pz, __int_as_float(i));
-  o4[i] = make_float4(px, py, pz, 0.f);
+__device__ __forceinline__ void grid_tscatter_body(const TscatterArgs& a, const int block) {
+  const int i = block * blockDim.x + threadIdx.x;
+  if (i >= a.n) return;
+  const float px = a.x[i], py = a.y[i], pz = a.z[i];
+  a.t4[a.cell_start[a.tcell[i]] + a.tslot[i]] = make_float4(px, py, pz, __int_as_float(i));
+  a.o4[i] = make_float4(px, py, pz, 0.f);
+}
+__global__ void grid_tscatter_kernel(const TscatterArgs a) { grid_tscatter_body(a, blockIdx.x); }
+__global__ void grid_tscatter_batch_kernel(const SetupBatchOf<TscatterArgs> b) { grid_tscatter_body(b.p[blockIdx.y], blockIdx.x); }
+
+template <typename A>
+static int max_n(const SetupBatchOf<A>& b, int count) {
+  int m = 0;
+  for (int k = 0; k < count; ++k) m = b.p[k].n > m ? b.p[k].n : m;
+  return m;
 }
 
 void launch_grid_tscatter(const float* x, const float* y, const float* z, const int* tcell, const int* tslot,
                           const int* cell_start, int n, float4* t4, float4* o4, hipStream_t s) {
   if (n <= 0) return;
-  hipLaunchKernelGGL(grid_tscatter_kernel, dim3((n + 255) / 256), dim3(256), 0, s, x, y, z, tcell, tslot, cell_start,
-                     n, t4, o4);
+  const TscatterArgs a{x, y, z, tcell, tslot, cell_start, t4, o4, n, 0};
+  ICPK_RECORD(SK_TSCATTER, tscatter, a)
+  hipLaunchKernelGGL(grid_tscatter_kernel, dim3((n + 255) / 256), dim3(256), 0, s, a);
+}
+void launch_grid_tscatter_batch(const SetupBatchOf<TscatterArgs>& b, int count, hipStream_t s) {
+  const int m = max_n(b, count);
+  if (count > 0 && m > 0) hipLaunchKernelGGL(grid_tscatter_batch_kernel, dim3((m + 255) / 256, count), dim3(256), 0, s, b);
 }
 
 void launch_grid_qslot(const float* x, const float* y, const float* z, int n, const GridInfo* g, int* count, int* qcell,
                        int* qslot, int coarse, hipStream_t s) {
   if (n <= 0) return;
-  hipLaunchKernelGGL(grid_qslot_kernel, dim3((n + 255) / 256), dim3(256), 0, s, x, y, z, n, g, count, qcell, qslot,
-                     coarse);
+  const QslotArgs a{x, y, z, g, count, qcell, qslot, n, coarse};
+  ICPK_RECORD(SK_QSLOT, qslot, a)
+  hipLaunchKernelGGL(grid_qslot_kernel, dim3((n + 255) / 256), dim3(256), 0, s, a);
+}
+void launch_grid_qslot_batch(const SetupBatchOf<QslotArgs>& b, int count, hipStream_t s) {
+  const int m = max_n(b, count);
+  if (count > 0 && m > 0) hipLaunchKernelGGL(grid_qslot_batch_kernel, dim3((m + 255) / 256, count), dim3(256), 0, s, b);
 }
 void launch_grid_qscatter(const int* qcell, const int* qslot, const int* qstart, int n, int* qperm, const float* qx,
                           const float* qy, const float* qz, const float* ox, const float* oy, const float* oz,
                           float4* qm4, float4* sp, nn_key_t* seed_m, hipStream_t s) {
   if (n <= 0) return;
-  hipLaunchKernelGGL(grid_qscatter_kernel, dim3((n + 255) / 256), dim3(256), 0, s, qcell, qslot, qstart, n, qperm, qx, qy,
-                     qz, ox, oy, oz, qm4, sp, seed_m);
+  const QscatterArgs a{qcell, qslot, qstart, qperm, qx, qy, qz, ox, oy, oz, qm4, sp, seed_m, n, 0};
+  ICPK_RECORD(SK_QSCATTER, qscatter, a)
+  hipLaunchKernelGGL(grid_qscatter_kernel, dim3((n + 255) / 256), dim3(256), 0, s, a);
+}
+void launch_grid_qscatter_batch(const SetupBatchOf<QscatterArgs>& b, int count, hipStream_t s) {
+  const int m = max_n(b, count);
+  if (count > 0 && m > 0) hipLaunchKernelGGL(grid_qscatter_batch_kernel, dim3((m + 255) / 256, count), dim3(256), 0, s, b);
 }
 
 int grid_bounds_parts(int n) {  // one 1024-thread block per 2048 points, at most GRID_BOUNDS_PARTS
@@ -306,11 +355,24 @@ int grid_bounds_parts(int n) {  // one 1024-thread block per 2048 points, at mos
   return nb < 1 ? 1 : (nb > GRID_BOUNDS_PARTS ? GRID_BOUNDS_PARTS : nb);
 }
 void launch_grid_bounds(const float* x, const float* y, const float* z, int n, float* fb, hipStream_t s) {
-  hipLaunchKernelGGL(grid_bounds_kernel, dim3(grid_bounds_parts(n)), dim3(1024), 0, s, x, y, z, n, fb);
+  const BoundsArgs a{x, y, z, fb, n, grid_bounds_parts(n)};
+  ICPK_RECORD(SK_BOUNDS, bounds, a)
+  hipLaunchKernelGGL(grid_bounds_kernel, dim3(a.nparts), dim3(1024), 0, s, a);
+}
+void launch_grid_bounds_batch(const SetupBatchOf<BoundsArgs>& b, int count, hipStream_t s) {
+  int m = 0;
+  for (int k = 0; k < count; ++k) m = b.p[k].nparts > m ? b.p[k].nparts : m;
+  if (count > 0 && m > 0) hipLaunchKernelGGL(grid_bounds_batch_kernel, dim3(m, count), dim3(1024), 0, s, b);
 }
 void launch_grid_info(const float* fb, int n, float ppc, int xdiv, GridInfo* g, hipStream_t s) {
-  hipLaunchKernelGGL(grid_info_kernel, dim3(1), dim3(64), 0, s, fb, grid_bounds_parts(n), n, ppc, xdiv < 1 ? 1 : xdiv, g);
+  const InfoArgs a{fb, g, grid_bounds_parts(n), n, ppc, xdiv < 1 ? 1 : xdiv};
+  ICPK_RECORD(SK_INFO, info, a)
+  hipLaunchKernelGGL(grid_info_kernel, dim3(1), dim3(64), 0, s, a);
 }
+void launch_grid_info_batch(const SetupBatchOf<InfoArgs>& b, int count, hipStream_t s) {
+  if (count > 0) hipLaunchKernelGGL(grid_info_batch_kernel, dim3(count), dim3(64), 0, s, b);
+}
+#undef ICPK_RECORD
 
 // ---- the sweep --------------------------------------------------------------------------
 // Cells met by the cube [q - rr, q + rr], rr slightly above the current best distance r.

@@ -229,6 +229,46 @@ __global__ __launch_bounds__(256) void loop_step_batch_kernel(const StepBatch b,
   loop_step_body<NS, NACT>(a.partial, a.pcount, a.nblocks, a.st, stats_only);
 }
 
+// initial LoopState (everything in front of the trace arrays) from values that travel in the kernel
+// arguments: no staging copy, and one launch for a whole lock-step group
+__device__ __forceinline__ void loop_init_body(const LoopInitArgs& a) {
+  constexpr int WORDS = (int)(offsetof(LoopState, trace_R) / 4);
+  int* w = reinterpret_cast<int*>(a.st);
+  for (int i = threadIdx.x; i < WORDS; i += blockDim.x) w[i] = 0;
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  LoopState* st = a.st;
+  st->Trot[0] = st->Trot[4] = st->Trot[8] = 1.f;
+  st->Tk[0] = st->Tk[5] = st->Tk[10] = 1.0;
+  st->max_iterations = a.max_iterations;
+  st->min_pairs = a.min_pairs;
+  st->solve = a.solve;
+  st->fixed_iterations = a.fixed_iterations;
+  st->threshold = a.threshold;
+  st->epoch = a.epoch;
+  st->progress = a.progress;
+  for (int k = 0; k < 9; ++k) st->last_rotation[k] = a.last_rotation[k];
+  for (int k = 0; k < 3; ++k) st->last_translation[k] = a.last_translation[k];
+}
+__global__ __launch_bounds__(64) void loop_init_kernel(const LoopInitArgs a) { loop_init_body(a); }
+__global__ __launch_bounds__(64) void loop_init_batch_kernel(const SetupBatchOf<LoopInitArgs> b) { loop_init_body(b.p[blockIdx.x]); }
+
+void launch_loop_init(const LoopInitArgs& a, hipStream_t s) {
+  if (SetupRecorder* r = setup_recorder()) {
+    if (r->n < 24) {
+      r->calls[r->n].kind = SK_LOOP_INIT;
+      r->calls[r->n++].loop_init = a;
+    } else {
+      r->overflow = true;
+    }
+    return;
+  }
+  hipLaunchKernelGGL(loop_init_kernel, dim3(1), dim3(64), 0, s, a);
+}
+void launch_loop_init_batch(const SetupBatchOf<LoopInitArgs>& b, int count, hipStream_t s) {
+  if (count > 0) hipLaunchKernelGGL(loop_init_batch_kernel, dim3(count), dim3(64), 0, s, b);
+}
+
 void launch_loop_step(const double* partial, const int* pcount, int nblocks, int nsum, LoopState* st, int stats_only,
                       hipStream_t s) {
   if (nsum == NP2L)

@@ -59,31 +59,57 @@ void launch_fill_f32(float* p, int n, float v, hipStream_t s) {
 // may lie anywhere, into the context's plane layout, padded up to n_pad with `pad`, and, for a source
 // cloud, into the working copy as well -- ONE launch instead of three copies, three fills and the
 // copy of the working source.  d2 == nullptr: one destination.
-__global__ __launch_bounds__(256) void ingest_cloud_kernel(const float* __restrict__ x, const float* __restrict__ y,
-                                                           const float* __restrict__ z, int n, int n_pad, float pad,
-                                                           float* __restrict__ d1, int cap1, float* __restrict__ d2,
-                                                           int cap2) {
-  const int stride = gridDim.x * blockDim.x;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_pad; i += stride) {
-    const bool in = i < n;
-    const float vx = in ? x[i] : pad, vy = in ? y[i] : pad, vz = in ? z[i] : pad;
-    d1[i] = vx;
-    d1[(size_t)cap1 + i] = vy;
-    d1[2 * (size_t)cap1 + i] = vz;
-    if (d2) {
-      d2[i] = vx;
-      d2[(size_t)cap2 + i] = vy;
-      d2[2 * (size_t)cap2 + i] = vz;
+__device__ __forceinline__ void ingest_cloud_body(const IngestArgs& a, int block, int nblocks) {
+  const int stride = nblocks * 256;
+  for (int i = block * 256 + threadIdx.x; i < a.n_pad; i += stride) {
+    const bool in = i < a.n;
+    const float vx = in ? a.x[i] : a.pad, vy = in ? a.y[i] : a.pad, vz = in ? a.z[i] : a.pad;
+    a.d1[i] = vx;
+    a.d1[(size_t)a.cap1 + i] = vy;
+    a.d1[2 * (size_t)a.cap1 + i] = vz;
+    if (a.d2) {
+      a.d2[i] = vx;
+      a.d2[(size_t)a.cap2 + i] = vy;
+      a.d2[2 * (size_t)a.cap2 + i] = vz;
     }
   }
+}
+
+__global__ __launch_bounds__(256) void ingest_cloud_kernel(const IngestArgs a) { ingest_cloud_body(a, blockIdx.x, gridDim.x); }
+
+// frame-batch set-up: blockIdx.y = cloud of the group
+__global__ __launch_bounds__(256) void ingest_cloud_batch_kernel(const SetupBatchOf<IngestArgs> b) {
+  ingest_cloud_body(b.p[blockIdx.y], blockIdx.x, gridDim.x);
+}
+
+static inline int ingest_blocks(int n_pad) {
+  int blocks = (n_pad + 255) / 256;
+  return blocks > 2048 ? 2048 : blocks;
 }
 
 void launch_ingest_cloud(const float* x, const float* y, const float* z, int n, int n_pad, float pad, float* d1, int cap1,
                          float* d2, int cap2, hipStream_t s) {
   if (n_pad <= 0) return;
-  int blocks = (n_pad + 255) / 256;
-  if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(ingest_cloud_kernel, dim3(blocks), dim3(256), 0, s, x, y, z, n, n_pad, pad, d1, cap1, d2, cap2);
+  IngestArgs a{x, y, z, n, n_pad, pad, cap1, d1, d2, cap2, 0};
+  if (SetupRecorder* r = setup_recorder()) {
+    if (r->n < 24) {
+      r->calls[r->n].kind = SK_INGEST;
+      r->calls[r->n++].ingest = a;
+    } else {
+      r->overflow = true;
+    }
+    return;
+  }
+  hipLaunchKernelGGL(ingest_cloud_kernel, dim3(ingest_blocks(n_pad)), dim3(256), 0, s, a);
+}
+
+void launch_ingest_batch(const SetupBatchOf<IngestArgs>& b, int count, hipStream_t s) {
+  int m = 0;
+  for (int k = 0; k < count; ++k) m = b.p[k].n_pad > m ? b.p[k].n_pad : m;
+  if (count <= 0 || m <= 0) return;
+  int blocks = ingest_blocks(m);
+  if (blocks > 512) blocks = 512;  // (x count clouds: plenty of workgroups; the body strides)
+  hipLaunchKernelGGL(ingest_cloud_batch_kernel, dim3(blocks, count), dim3(256), 0, s, b);
 }
 
 }  // namespace icpk
