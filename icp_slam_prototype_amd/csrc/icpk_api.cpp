@@ -360,7 +360,10 @@ int prepare_sorted_sweep(icpk_ctx* ctx, int nn_mode, NnArgs& a, NnBoxes& bx, int
     bx.ox = ctx->tgt.x();
     bx.oy = ctx->tgt.y();
     bx.oz = ctx->tgt.z();
-    rc = prepare_grid_target(ctx);
+    // (one size for both counting sorts up front: the target's sort must not see its scratch re-allocated by
+    // the queries' -- its launches may only have been recorded so far, see SetupRecorder)
+    rc = ensure_sort_buffers(ctx, nq > ctx->tgt.n ? nq : ctx->tgt.n);
+    if (!rc) rc = prepare_grid_target(ctx);
     if (!rc) rc = ensure_query_points(ctx, nq);
   } else {
     rc = prepare_pruned_target(ctx, bx);
@@ -797,7 +800,7 @@ int icpk_create(icpk_ctx** out, int device_id) {
     const int v = std::atoi(e);
     if (v >= 1 && v <= 16) ctx->batch_threads = v;
   }
-  if (const char* e = std::getenv("ICPK_BATCH_SETUP")) ctx->batch_setup = std::atoi(e) != 0;
+  if (const char* e = std::getenv("ICPK_BATCH_SETUP")) ctx->batch_setup = std::atoi(e);  // 0: per-pair launches; 2: batched launches for single-group host-pointer batches too
   if (const char* e = std::getenv("ICPK_LOOP_AHEAD")) {  // 0: enqueue every iteration up front
     const int v = std::atoi(e);
     if (v >= 0 && v <= LOOP_MAX_ITER) ctx->loop_ahead = v;
@@ -1773,7 +1776,10 @@ int align_batch_impl(icpk_ctx* ctx, int32_t n_pairs, const icpk_pair* pairs, con
     // Device-resident pairs: the set-up launches of the whole group are RECORDED (icpk_internal.h, SetupRecorder)
     // and issued as one launch per step on the set's set-up stream -- 13 launches instead of 13 per pair.
     std::vector<bool> recorded(g.count, false);
-    const bool batched = kind == hipMemcpyDeviceToDevice && ctx->batch_setup != 0;
+    // (host buffers: only when several groups follow each other -- 64 pairs 20.4 -> 17.8 ms; for a single group
+    // the uploads of the pairs would queue up on the one set-up stream in front of everything else: 8 pairs
+    // 3.1 -> 3.3 ms, tools/probe_host_batch.py)
+    const bool batched = ctx->batch_setup != 0 && (kind == hipMemcpyDeviceToDevice || ngroups > 1 || ctx->batch_setup == 2);
     // (host buffers: one thread -- concurrent host-to-device copies from several threads stall for
     // ~9 ms at random on this runtime, tools/one_align.py --batch under ICPK_BATCH_TRACE)
     const int nthreads = batched || kind == hipMemcpyHostToDevice ? 1 : (g.count < ctx->batch_threads ? g.count : ctx->batch_threads);

@@ -194,6 +194,43 @@ def test_device_resident_pairs(ctx):
         hip.free()
 
 
+@pytest.mark.parametrize("setup", ["0", "1", "2"])
+def test_ragged_pairs_on_fresh_contexts_with_and_without_batched_setup(monkeypatch, setup):
+    """The set-up launches of a lock-step group are recorded and issued once per step for all pairs
+    (SetupRecorder, ICPK_BATCH_SETUP).  Recorded arguments hold pointers, so nothing they point at may be
+    re-allocated between recording and the flush: fresh contexts (every capacity zero), sources LARGER than
+    their targets (the queries' counting sort outgrowing the scratch the target's sort was recorded with
+    is what a soak run caught), sizes that differ pair to pair, several groups, host and device buffers."""
+    monkeypatch.setenv("ICPK_BATCH_SETUP", setup)
+    monkeypatch.setenv("ICPK_BATCH_GROUP", "4")
+    rng = np.random.default_rng(5)
+    pairs = []
+    for k in range(11):
+        nt, nq = int(rng.integers(300, 4000)), int(rng.integers(300, 4000))
+        if k % 2 == 0:
+            nq = nt + int(rng.integers(2000, 9000)) + 1500 * k  # ever larger sources: re-allocation in every group
+        tgt = (rng.uniform(-1, 1, (3, nt)) + 5).astype(np.float32)
+        src = (tgt[:, rng.integers(0, nt, nq)] + rng.normal(0, 0.01, (3, nq))).astype(np.float32)
+        pairs.append((src, tgt))
+    kw = dict(max_iterations=5, fixed_iterations=1, max_nn_dist=0.2)
+    with binding.Context(0) as single:
+        want = _single(single, pairs, **kw)
+    hip = _Hip()
+    try:
+        dev = [(hip.upload(s), s.shape[1], hip.upload(t), t.shape[1]) for s, t in pairs]
+        with binding.Context(0) as a:  # device buffers first: every slot capacity starts at zero
+            Td, std, rcd = a.align_batch_device(dev, **kw)
+        with binding.Context(0) as b:
+            Th, sth, rch, assoc = b.align_batch(pairs, associations=True, **kw)
+    finally:
+        hip.free()
+    for k, (Tw, stw, rcw, idx, dist, _) in enumerate(want):
+        for T, st in ((Td[k], std[k]), (Th[k], sth[k])):
+            assert np.array_equal(T, Tw), k
+            assert (st.iterations, st.status, st.final_pairs) == (stw.iterations, stw.status, stw.final_pairs), k
+        assert np.array_equal(assoc[k][0], idx) and np.array_equal(assoc[k][1].view(np.uint32), dist.view(np.uint32)), k
+
+
 def test_other_kernels_and_flavours_run_pair_by_pair(ctx):
     """Settings outside the lock-step path (another NN kernel, host loop) still give the same
     results through icpk_align_batch, one pair after the other."""

@@ -4,6 +4,11 @@ pair sizes (1 ... 30k points), both lock-step flavours, threshold exits, far-apa
 empty sources.  usage: python tools/soak_batch.py [n_batches] [seed0]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+DEVICE = "--device" in sys.argv  # pairs resident in HBM through icpk_align_batch_device (no associations read back)
+if DEVICE:
+    sys.argv.remove("--device")
+    import torch  # first: its HIP runtime must be the one libicpk.so binds to
+    torch.cuda.init()
 import numpy as np
 from icp_slam_prototype_amd import binding, synth
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
@@ -47,14 +52,21 @@ for c in range(n_batches):
         pairs.append((np.ascontiguousarray(s, np.float32), np.ascontiguousarray(t, np.float32)))
     kw = dict(solve=int(rng.integers(0, 2)), max_iterations=int(rng.integers(0, 12)), fixed_iterations=int(rng.random() < 0.5),
               max_nn_dist=float(rng.choice([0.75, 0.1, 0.02])), last_translation=rng.normal(0, 0.1, 3).astype(np.float32))
-    T, st, rc, assoc = ctx.align_batch(pairs, associations=True, **kw)
+    if DEVICE:
+        keep = [(torch.from_numpy(s).cuda(), torch.from_numpy(t).cuda()) for s, t in pairs]
+        torch.cuda.synchronize()
+        args = [(a.data_ptr(), a.shape[1], b_.data_ptr(), b_.shape[1]) for a, b_ in keep]
+        T, st, rc = ctx.align_batch_device(args, binding.default_params(**kw))
+        assoc = None
+    else:
+        T, st, rc, assoc = ctx.align_batch(pairs, associations=True, **kw)
     for b, (s, t) in enumerate(pairs):
         single.set_target(t)
         single.set_source(s)
         Ts, sts, rcs = single.align(**kw)
         ok = np.array_equal(T[b].view(np.uint32), Ts.view(np.uint32)) and (st[b].iterations, st[b].status, st[b].final_pairs) == (
             sts.iterations, sts.status, sts.final_pairs)
-        if s.shape[1] > 0:
+        if s.shape[1] > 0 and assoc is not None:
             i1, d1 = single.get_associations()
             ok = ok and np.array_equal(assoc[b][0], i1) and np.array_equal(assoc[b][1].view(np.uint32), d1.view(np.uint32))
         if not ok:
