@@ -821,7 +821,7 @@ void icpk_destroy(icpk_ctx* ctx) {
   for (hipEvent_t e : {ctx->ready_ev, ctx->group_ev[0], ctx->group_ev[1], ctx->setup_ev[0], ctx->setup_ev[1]})
     if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : ctx->events) (void)hipEventDestroy(e);
-  void* dev[] = {ctx->qcount, ctx->qstart, ctx->scan_bsum, ctx->qm4, ctx->sp_in, ctx->sp_out, ctx->grid_info, ctx->grid_bounds, ctx->cell_start, ctx->t4, ctx->o4, ctx->best_m, ctx->seed_m, ctx->st_dev, ctx->sorted.base, ctx->tkeys, ctx->tperm, ctx->qperm, ctx->bounds, ctx->sort_keys, ctx->sort_vals, ctx->sort_temp,
+  void* dev[] = {ctx->qcount, ctx->qstart, ctx->scan_bsum, ctx->qm4, ctx->sp_in, ctx->sp_out, ctx->grid_info, ctx->grid_bounds, ctx->cell_start, ctx->t4, ctx->o4, ctx->best_m, ctx->seed_m, ctx->st_pooled ? nullptr : (void*)ctx->st_dev, ctx->sorted.base, ctx->tkeys, ctx->tperm, ctx->qperm, ctx->bounds, ctx->sort_keys, ctx->sort_vals, ctx->sort_temp,
                  ctx->nrm.base, ctx->boxes, ctx->dec.base, ctx->tgt.base, ctx->src0.base, ctx->src.base, ctx->best,      ctx->seed,     ctx->idx,
                  ctx->dist,     ctx->partial,   ctx->pcount,   ctx->red_out,   ctx->depth_dev, ctx->depth_flt, ctx->ks_buf, ctx->bp_counts};
   for (void* p : dev)
@@ -830,7 +830,9 @@ void icpk_destroy(icpk_ctx* ctx) {
   if (ctx->stage_t) (void)hipHostFree(ctx->stage_t);
   if (ctx->stage_s) (void)hipHostFree(ctx->stage_s);
   if (ctx->bp_n_host) (void)hipHostFree(ctx->bp_n_host);
-  if (ctx->st_host) (void)hipHostFree(ctx->st_host);
+  if (ctx->st_host && !ctx->st_pooled) (void)hipHostFree(ctx->st_host);
+  if (ctx->slot_states) (void)hipFree(ctx->slot_states);
+  if (ctx->slot_states_host) (void)hipHostFree(ctx->slot_states_host);
   if (ctx->progress) (void)hipHostFree(ctx->progress);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -1515,9 +1517,21 @@ bool batch_eligible(const icpk_ctx* ctx, const icpk_params* p) {
 }
 
 int ensure_slots(icpk_ctx* ctx, int n) {
+  if (n > 2 * BATCH_MAX) return fail(ctx, ICPK_E_ARG, "too many frame-batch slots");
+  if (!ctx->slot_states) {
+    ICPK_HIP(ctx, hipMalloc((void**)&ctx->slot_states, (size_t)2 * BATCH_MAX * sizeof(LoopState)));
+    ICPK_HIP(ctx, hipHostMalloc((void**)&ctx->slot_states_host, (size_t)2 * BATCH_MAX * sizeof(LoopState), hipHostMallocDefault));
+  }
   while ((int)ctx->slots.size() < n) {
     icpk_ctx* sl = make_context(ctx->device, ctx);
     if (!sl) return fail(ctx, ICPK_E_HIP, "frame-batch slot allocation failed");
+    // the slot's loop state lives in the parent's pools (one copy brings a whole group's states back)
+    const size_t k = ctx->slots.size();
+    (void)hipFree(sl->st_dev);
+    (void)hipHostFree(sl->st_host);
+    sl->st_dev = ctx->slot_states + k;
+    sl->st_host = ctx->slot_states_host + k;
+    sl->st_pooled = true;
     ctx->slots.push_back(sl);
   }
   return ICPK_OK;
@@ -1657,8 +1671,16 @@ int enqueue_group_loop(icpk_ctx* ctx, const icpk_params* p, const std::vector<ic
   }
   launch_loop_step_batch(sb, n, nsum, 1, ctx->stream);
   ICPK_HIP(ctx, hipGetLastError());
-  for (icpk_ctx* sl : act)
-    ICPK_HIP(ctx, hipMemcpyAsync(sl->st_host, sl->st_dev, sizeof(LoopState), hipMemcpyDeviceToHost, ctx->stream));
+  {  // the group's loop states: ONE copy (the slots' states are consecutive entries of the parent's pool)
+    size_t lo = (size_t)-1, hi = 0;
+    for (icpk_ctx* sl : act) {
+      const size_t k = (size_t)(sl->st_dev - ctx->slot_states);
+      lo = k < lo ? k : lo;
+      hi = k > hi ? k : hi;
+    }
+    ICPK_HIP(ctx, hipMemcpyAsync(ctx->slot_states_host + lo, ctx->slot_states + lo, (hi - lo + 1) * sizeof(LoopState),
+                                 hipMemcpyDeviceToHost, ctx->stream));
+  }
   ICPK_HIP(ctx, hipEventRecord(ctx->group_ev[set], ctx->stream));
   return ICPK_OK;
 }

@@ -111,6 +111,9 @@ struct icpk_ctx {
   hipEvent_t group_ev[2] = {nullptr, nullptr};  // parent: the lock-step loop of a slot set has finished
   hipStream_t setup_stream[2] = {nullptr, nullptr};  // parent: the batched set-up launches of a slot set (created on first use)
   hipEvent_t setup_ev[2] = {nullptr, nullptr};       // ... and their completion
+  LoopState* slot_states = nullptr;       // parent: the loop states of all slots in one allocation (slot k at [k]),
+  LoopState* slot_states_host = nullptr;  //   so that a group's states come back with ONE copy; pinned mirror
+  bool st_pooled = false;                 // slot: st_dev / st_host point into the parent's pools
   int batch_setup = 1;                               // 0 (ICPK_BATCH_SETUP=0): per-pair set-up launches on the slots' own streams
   int batch_group = 16;                // pairs advancing in lock step (ICPK_BATCH_GROUP, <= BATCH_MAX)
   int batch_threads = 4;               // host threads sharing a group's set-up calls (ICPK_BATCH_THREADS)
