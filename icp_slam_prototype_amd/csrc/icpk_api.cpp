@@ -800,7 +800,7 @@ int icpk_create(icpk_ctx** out, int device_id) {
     const int v = std::atoi(e);
     if (v >= 1 && v <= 16) ctx->batch_threads = v;
   }
-  if (const char* e = std::getenv("ICPK_BATCH_SETUP")) ctx->batch_setup = std::atoi(e);  // 0: per-pair launches; 2: batched launches for single-group host-pointer batches too
+  if (const char* e = std::getenv("ICPK_BATCH_SETUP")) ctx->batch_setup = std::atoi(e);  // 0: per-pair launches; 2: batched launches for single-group host-pointer batches too; 3: as 2, replayed pair by pair
   if (const char* e = std::getenv("ICPK_LOOP_AHEAD")) {  // 0: enqueue every iteration up front
     const int v = std::atoi(e);
     if (v >= 0 && v <= LOOP_MAX_ITER) ctx->loop_ahead = v;
@@ -1801,7 +1801,7 @@ int align_batch_impl(icpk_ctx* ctx, int32_t n_pairs, const icpk_pair* pairs, con
     // (host buffers: only when several groups follow each other -- 64 pairs 20.4 -> 17.8 ms; for a single group
     // the uploads of the pairs would queue up on the one set-up stream in front of everything else: 8 pairs
     // 3.1 -> 3.3 ms, tools/probe_host_batch.py)
-    const bool batched = ctx->batch_setup != 0 && (kind == hipMemcpyDeviceToDevice || ngroups > 1 || ctx->batch_setup == 2);
+    const bool batched = ctx->batch_setup != 0 && (kind == hipMemcpyDeviceToDevice || ngroups > 1 || ctx->batch_setup >= 2);
     // (host buffers: one thread -- concurrent host-to-device copies from several threads stall for
     // ~9 ms at random on this runtime, tools/one_align.py --batch under ICPK_BATCH_TRACE)
     const int nthreads = batched || kind == hipMemcpyHostToDevice ? 1 : (g.count < ctx->batch_threads ? g.count : ctx->batch_threads);
@@ -1830,7 +1830,7 @@ int align_batch_impl(icpk_ctx* ctx, int32_t n_pairs, const icpk_pair* pairs, con
       for (int k = 0; k < g.count; ++k)
         if (recorded[k]) ok.push_back(recs[k]);
       if (!ok.empty()) {
-        if (!flush_setup_batches(ok.data(), (int)ok.size(), ss))
+        if (ctx->batch_setup == 3 /* test hook: the pair-by-pair replay */ || !flush_setup_batches(ok.data(), (int)ok.size(), ss))
           for (const SetupRecorder& r : ok) replay_setup(r, ss);
         ICPK_HIP(ctx, hipGetLastError());
         ICPK_HIP(ctx, hipEventRecord(ctx->setup_ev[g.set], ss));

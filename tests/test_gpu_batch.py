@@ -194,7 +194,7 @@ def test_device_resident_pairs(ctx):
         hip.free()
 
 
-@pytest.mark.parametrize("setup", ["0", "1", "2"])
+@pytest.mark.parametrize("setup", ["0", "1", "2", "3"])  # 3: recorded, then replayed pair by pair (the fall-back)
 def test_ragged_pairs_on_fresh_contexts_with_and_without_batched_setup(monkeypatch, setup):
     """The set-up launches of a lock-step group are recorded and issued once per step for all pairs
     (SetupRecorder, ICPK_BATCH_SETUP).  Recorded arguments hold pointers, so nothing they point at may be
