@@ -1882,6 +1882,9 @@ int align_batch_impl(icpk_ctx* ctx, int32_t n_pairs, const icpk_pair* pairs, con
   // has been waited for.  Only slots whose set-up FAILED may still have copies in flight.
   ICPK_HIP(ctx, hipStreamSynchronize(ctx->stream));
   for (icpk_ctx* sl : unfinished) ICPK_HIP(ctx, hipStreamSynchronize(sl->stream));
+  if (!unfinished.empty())  // (with the batched set-up their uploads went to the set's set-up stream)
+    for (hipStream_t st : {ctx->setup_stream[0], ctx->setup_stream[1]})
+      if (st) ICPK_HIP(ctx, hipStreamSynchronize(st));
   if (trace) std::fprintf(stderr, "icpk batch tail: wait+finish last group %.0f us, stream syncs %.0f us\n", us(te0, te1), us(te1, now()));
   return worst;
 }
