@@ -270,6 +270,44 @@ def roofline_blocks(workload, nn_mode, nq, nt, avg_nn_s, timing, kernel):
     return phys, yard
 
 
+def batch_roofline(stats, group, pairs_per_launch_hint=None):
+    """Physical roofline of the lock-step group's NN kernel (nn_grid_batch_kernel) from the launches
+    icpk_align_batch bracketed with HIP events (params.profile = 1: one batched launch per group, booked on
+    the group's first pair, covering all its pairs) and the per-pair counter figures of
+    profiles/hbm_traffic.json["frame_batch8:grid"] (a group of 8 config-2 pairs under rocprofv3 --pmc)."""
+    e = pmc_entry("frame_batch8", "grid")
+    t = 0.0
+    pair_launches = 0  # pairs covered by the timed launches
+    launches = 0
+    for call in stats:  # one list of per-pair stats per profiled call
+        n = len(call)
+        for g0 in range(0, n, group):
+            s = call[g0]
+            if s.nn_timed_launches >= 1:
+                t += s.nn_ms_total / 1e3
+                pair_launches += min(group, n - g0)
+                launches += 1
+    if launches == 0 or t <= 0:
+        return None
+    out = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+           "kernel": "nn_grid_batch_kernel<4,false|true>", "avg_launch_ms": t / launches * 1e3,
+           "pairs_per_launch": pair_launches / launches,
+           "timing": f"two HIP events around ONE batched NN launch per lock-step group, its position among the group's 21 "
+                     f"sweeps rotating ({launches} launches over {len(stats)} extra calls after the timed ones; the next group's "
+                     "set-up runs beside it on another stream, and the event pair costs ~4 us)"}
+    if e:
+        per_pair = float(e["hbm_bytes_per_launch"]) / 8.0
+        v_pair = float(e.get("valu_insts_per_launch") or 0.0) / 8.0
+        traffic = per_pair * pair_launches / launches
+        out.update({"traffic": traffic, "achieved": per_pair * pair_launches / t / 1e9,
+                    "frac": per_pair * pair_launches / t / 1e9 / HBM_PEAK_GBS,
+                    "traffic_source": "profiles/hbm_traffic.json[frame_batch8:grid] / 8 pairs x pairs per launch "
+                                      "(tools/collect_counters.py: (2 x FETCH_SIZE + WRITE_SIZE) KB, separate --pmc passes)"})
+        if v_pair:
+            out["valu_issue_frac"] = v_pair * pair_launches / (N_SIMD * VALU_ISSUE_PER_SIMD * t)
+    return out
+
+
 # ------------------------------------------------------------------------------- helpers --
 def upload(torch, dev, a):
     return torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev)
@@ -442,6 +480,10 @@ def frame_batch_one_gpu(args, torch, dev, gpu_index, single_value):
     gc.enable()
     dt = statistics.median(each)
     total_iters = sum(s.iterations for s in st)
+    params.profile = 1  # a few more calls, outside the timed ones: a bracketed NN launch per group
+    prof = [ctx.align_batch_device(pargs, params)[1] for _ in range(6)]
+    params.profile = 0
+    roof = batch_roofline(prof, int(os.environ.get("ICPK_BATCH_GROUP", "16")))
     # PCIe-inclusive (never a headline): the same call with HOST buffers, as the reference would hand them
     # over (icpk_align_batch: every cloud crosses PCIe from pageable memory inside the call); 16 pairs
     nh = min(16, args.batch_pairs)
@@ -459,7 +501,7 @@ def frame_batch_one_gpu(args, torch, dev, gpu_index, single_value):
                         f"(lock-step groups of {os.environ.get('ICPK_BATCH_GROUP', '16')})",
             "value": total_iters / dt, "unit": "iter/s", "ms_per_batch": dt * 1e3, "ms_per_pair": dt * 1e3 / args.batch_pairs,
             "vs_single_pair": total_iters / dt / single_value, "pcie_inclusive_iter_s": pcie_rate, "reps": reps, "timing": "median of 5 calls, host wall clock, "
-            "device idle before and after each call", "ms_each": [round(t * 1e3, 3) for t in each]}
+            "device idle before and after each call", "ms_each": [round(t * 1e3, 3) for t in each], "roofline": roof}
 
 
 def extra_workload(args, torch, dev, gpu_index, name, iters, steps):
@@ -617,6 +659,14 @@ def bench_frame_batch(args, torch, dist, rank, world, dev, cdev, gpu_index, rehe
     dist.all_reduce(lo, op=dist.ReduceOp.MIN)
     dist.all_reduce(hi, op=dist.ReduceOp.MAX)
     consistent = bool(torch.equal(lo, hi)) and rc == 0 and bool((Sg[:, 0] == args.iters).all()) and bool((Sg[:, 1] == 0).all())
+    roof = None
+    try:  # (auxiliary: never let it cost the line) one more call with a bracketed NN launch per group
+        params.profile = 1
+        prof = [ctx.align_batch_device(pargs, params)[1] for _ in range(6)]
+        params.profile = 0
+        roof = batch_roofline(prof, int(os.environ.get("ICPK_BATCH_GROUP", "16")))
+    except Exception as e:  # noqa: BLE001
+        roof = {"error": repr(e)}
     # key-frame broadcast (north_star: RCCL broadcast of the target cloud over xGMI), untimed
     # part of the run: rank 0's first target becomes every rank's target; median of 5
     bcast_ms = bcast_err = None
@@ -648,6 +698,7 @@ def bench_frame_batch(args, torch, dist, rank, world, dev, cdev, gpu_index, rehe
                        "frame_pairs_per_step": n_pairs, "pairs_per_gpu": count,
                        "parallelism": f"frame-batch x{world}: block partition, no per-iteration collective, one all-gather "
                                       f"of the results per step"},
+            "roofline": roof,
             "collectives": comm.kind, "collectives_fallback_reason": comm_err,
             "results_consistent_on_all_ranks": consistent,
             "keyframe_broadcast_ms": bcast_ms, "keyframe_broadcast_error": bcast_err,

@@ -818,7 +818,8 @@ void icpk_destroy(icpk_ctx* ctx) {
   ctx->slots.clear();
   for (hipStream_t st : {ctx->setup_stream[0], ctx->setup_stream[1]})
     if (st) (void)hipStreamDestroy(st);
-  for (hipEvent_t e : {ctx->ready_ev, ctx->group_ev[0], ctx->group_ev[1], ctx->setup_ev[0], ctx->setup_ev[1]})
+  for (hipEvent_t e : {ctx->ready_ev, ctx->group_ev[0], ctx->group_ev[1], ctx->setup_ev[0], ctx->setup_ev[1], ctx->batch_t0[0],
+                       ctx->batch_t0[1], ctx->batch_t1[0], ctx->batch_t1[1]})
     if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : ctx->events) (void)hipEventDestroy(e);
   void* dev[] = {ctx->qcount, ctx->qstart, ctx->scan_bsum, ctx->qm4, ctx->sp_in, ctx->sp_out, ctx->grid_info, ctx->grid_bounds, ctx->cell_start, ctx->t4, ctx->o4, ctx->best_m, ctx->seed_m, ctx->st_pooled ? nullptr : (void*)ctx->st_dev, ctx->sorted.base, ctx->tkeys, ctx->tperm, ctx->qperm, ctx->bounds, ctx->sort_keys, ctx->sort_vals, ctx->sort_temp,
@@ -1511,7 +1512,7 @@ struct GroupRun {
 };
 
 bool batch_eligible(const icpk_ctx* ctx, const icpk_params* p) {
-  return p->nn_mode == ICPK_NN_GRID && !p->host_loop && !ctx->log_fn && p->profile == 0 &&
+  return p->nn_mode == ICPK_NN_GRID && !p->host_loop && !ctx->log_fn && p->profile <= 1 &&
          (p->solve == ICPK_SOLVE_REFERENCE || p->solve == ICPK_SOLVE_KABSCH) && p->max_iterations >= 0 &&
          p->max_iterations <= LOOP_MAX_ITER;
 }
@@ -1647,7 +1648,24 @@ int enqueue_group_loop(icpk_ctx* ctx, const icpk_params* p, const std::vector<ic
     sb.p[k].nblocks = rb.p[k].nblocks;
     sb.p[k].st = act[k]->st_dev;
   }
-  launch_nn_grid_batch(gb, n, slices, 1, ctx->stream);  // icp.cpp:98 (expanding search from element 0)
+  // params.profile = 1: ONE of the group's max_iterations + 1 batched sweeps (rotating from group to group)
+  // is bracketed by two HIP events on this stream; finish_group adds the time to the group's first pair
+  int timed = -1;
+  ctx->batch_timed[set] = false;
+  if (p->profile == 1) {
+    for (hipEvent_t* e : {&ctx->batch_t0[set], &ctx->batch_t1[set]})
+      if (!*e) ICPK_HIP(ctx, hipEventCreate(e));
+    timed = ctx->profile_phase++ % (p->max_iterations + 1);
+    ctx->batch_timed[set] = true;
+  }
+  auto sweep = [&](int nth, int expand) -> int {
+    if (nth == timed) ICPK_HIP(ctx, hipEventRecord(ctx->batch_t0[set], ctx->stream));
+    launch_nn_grid_batch(gb, n, slices, expand, ctx->stream);
+    if (nth == timed) ICPK_HIP(ctx, hipEventRecord(ctx->batch_t1[set], ctx->stream));
+    return ICPK_OK;
+  };
+  int src_ = sweep(0, 1);  // icp.cpp:98 (expanding search from element 0)
+  if (src_) return src_;
   launch_assoc_reduce_batch(rb, n, p->max_nn_dist, nact, ctx->stream);
   for (int i = 0; i < p->max_iterations; ++i) {
     launch_loop_step_batch(sb, n, nsum, 0, ctx->stream);
@@ -1666,7 +1684,8 @@ int enqueue_group_loop(icpk_ctx* ctx, const icpk_params* p, const std::vector<ic
       sl->best_of_sweep.push_back(sl->best);
       rb.p[k].best = sl->best;
     }
-    launch_nn_grid_batch(gb, n, slices, 0, ctx->stream);  // icp.cpp:255, K3 fused
+    src_ = sweep(i + 1, 0);  // icp.cpp:255, K3 fused
+    if (src_) return src_;
     launch_assoc_reduce_batch(rb, n, p->max_nn_dist, nact, ctx->stream);
   }
   launch_loop_step_batch(sb, n, nsum, 1, ctx->stream);
@@ -1736,12 +1755,20 @@ int align_batch_impl(icpk_ctx* ctx, int32_t n_pairs, const icpk_pair* pairs, con
     bool any = false;
     for (int k = 0; k < g.count; ++k) any |= g.rc[k] == ICPK_OK;
     if (any) ICPK_HIP(ctx, hipEventSynchronize(ctx->group_ev[g.set]));
+    float timed_ms = -1.f;
+    if (any && ctx->batch_timed[g.set] && hipEventElapsedTime(&timed_ms, ctx->batch_t0[g.set], ctx->batch_t1[g.set]) != hipSuccess)
+      timed_ms = -1.f;
     for (int k = 0; k < g.count; ++k) {
       const int b = g.first + k;
       icpk_ctx* sl = ctx->slots[(size_t)g.set * G + k];
       int r = g.rc[k];
       if (r == ICPK_OK) {
         r = device_loop_finish(sl, p, T_out + 16 * (size_t)b, stats ? stats + b : nullptr);
+        if (stats && timed_ms >= 0.f) {  // the group's one timed launch, booked on its first pair (it covers ALL the group's pairs)
+          stats[b].nn_ms_total = timed_ms;
+          stats[b].nn_timed_launches = 1;
+          timed_ms = -1.f;
+        }
         if (r >= 0) {
           const int r2 = fetch_assoc(sl, pairs[b]);
           if (r2 < 0) r = r2;

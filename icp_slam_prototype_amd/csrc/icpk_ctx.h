@@ -111,6 +111,8 @@ struct icpk_ctx {
   hipEvent_t group_ev[2] = {nullptr, nullptr};  // parent: the lock-step loop of a slot set has finished
   hipStream_t setup_stream[2] = {nullptr, nullptr};  // parent: the batched set-up launches of a slot set (created on first use)
   hipEvent_t setup_ev[2] = {nullptr, nullptr};       // ... and their completion
+  hipEvent_t batch_t0[2] = {nullptr, nullptr}, batch_t1[2] = {nullptr, nullptr};  // parent: params.profile = 1 in the
+  bool batch_timed[2] = {false, false};                                           //   frame-batch mode: one sweep per group
   LoopState* slot_states = nullptr;       // parent: the loop states of all slots in one allocation (slot k at [k]),
   LoopState* slot_states_host = nullptr;  //   so that a group's states come back with ONE copy; pinned mirror
   bool st_pooled = false;                 // slot: st_dev / st_host point into the parent's pools

@@ -233,8 +233,10 @@ int icpk_get_trace(icpk_ctx *ctx, int32_t *n_iter, float *R_out, float *t_out, i
  * ICPK_BATCH_GROUP (default and at most 16) pairs advance in lock step -- one launch per stage
  * for the whole group -- while the next group is being uploaded and indexed; every pair's
  * result equals icpk_align on that pair bit for bit.  Other settings run the pairs one after
- * the other.  The context's own clouds are not touched by the lock-step path.  Per-launch
- * timings (params.profile) are not collected in this mode.
+ * the other.  The context's own clouds are not touched by the lock-step path.  params.profile = 1
+ * in this mode: ONE batched NN launch per group (its position rotating) is bracketed by HIP events;
+ * the time is booked on the group's first pair (stats.nn_ms_total, nn_timed_launches = 1) and covers
+ * ALL pairs of that group.
  * Returns the first negative status, else the max status. */
 int icpk_align_batch(icpk_ctx *ctx, int32_t n_pairs, const icpk_pair *pairs,
                      const icpk_params *p, float *T_out, icpk_stats *stats);
