@@ -163,20 +163,23 @@ def cpu_baseline_child(workload):
         idx, dist = o.nn_bruteforce(sub, tgt, threads=th)
         return time.perf_counter() - t0, idx, dist
 
-    # calibrate: one sample = `rounds` sweeps of m queries and lasts ~2.5 s
+    # one sample = whole sweeps of m queries until at least sample_s seconds have passed (timed, not
+    # calibrated: a box that is busy while calibrating must not end up with short samples)
     sweep(min(256, nq), threads)  # warm-up (thread team, caches)
     t_cal, _, _ = sweep(min(2048, nq), threads)
     sample_s = float(os.environ.get("ICPK_CPU_SAMPLE_S", "2.5"))  # seconds per sample (tests shorten it)
-    want = 2048 * sample_s / max(t_cal, 1e-4)     # queries per sample
-    m = int(min(nq, max(2048, want)))
-    rounds = max(1, int(round(want / m)))
+    m = int(min(nq, max(2048, 2048 * sample_s / max(t_cal, 1e-4))))
     samples = []
+    rounds_each = []
     for _ in range(5):
-        tt = 0.0
-        for _r in range(rounds):
+        tt, rounds = 0.0, 0
+        while tt < sample_s or rounds == 0:
             t, idx, dist = sweep(m, threads)
             tt += t
+            rounds += 1
         samples.append(tt / rounds * nq / m)
+        rounds_each.append(rounds)
+    rounds = statistics.median(rounds_each)
     t_nn = statistics.median(samples)
     # one thread: cost per pair of the scalar scan (BASELINE.md B1 stand-in)
     t1_cal, _, _ = sweep(min(128, nq), 1)
