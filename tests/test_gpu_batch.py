@@ -231,6 +231,27 @@ def test_ragged_pairs_on_fresh_contexts_with_and_without_batched_setup(monkeypat
         assert np.array_equal(assoc[k][0], idx) and np.array_equal(assoc[k][1].view(np.uint32), dist.view(np.uint32)), k
 
 
+def test_profile_in_the_frame_batch_mode_times_one_launch_per_group(monkeypatch):
+    """params.profile = 1 in the lock-step path: one batched NN launch per group is bracketed by HIP events and
+    booked on the group's first pair; results are the unprofiled ones."""
+    monkeypatch.setenv("ICPK_BATCH_GROUP", "3")
+    pairs = []
+    for k in range(7):
+        p = synth.kinect_pair(60, 80, valid=0.7, seed=900 + k)
+        pairs.append((p["source"], p["target"]))
+    with binding.Context(0) as c:
+        T0, st0, rc0 = c.align_batch(pairs, max_iterations=4, fixed_iterations=1)
+        T1, st1, rc1 = c.align_batch(pairs, max_iterations=4, fixed_iterations=1, profile=1)
+    assert rc0 == rc1 == 0 and np.array_equal(T0, T1)
+    for k in range(7):
+        assert (st1[k].iterations, st1[k].final_pairs) == (st0[k].iterations, st0[k].final_pairs)
+        if k % 3 == 0:  # first pair of a group of 3
+            assert st1[k].nn_timed_launches == 1 and 0.0 < st1[k].nn_ms_total < 50.0
+        else:
+            assert st1[k].nn_timed_launches == 0 and st1[k].nn_ms_total == 0.0
+        assert st0[k].nn_timed_launches == 0
+
+
 def test_other_kernels_and_flavours_run_pair_by_pair(ctx):
     """Settings outside the lock-step path (another NN kernel, host loop) still give the same
     results through icpk_align_batch, one pair after the other."""
