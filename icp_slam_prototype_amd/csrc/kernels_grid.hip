@@ -12,7 +12,7 @@
 // cube is a superset of every target that could tie or beat the seed (see cube_cells).
 //
 // Set-up (once per target cloud): finite bounds, cell size from the point density, counting
-// sort by cell (atomics + rocPRIM exclusive scan = the cell starts) into an AoS copy
+// sort by cell (slot by atomics + a device-sized exclusive scan = the cell starts) into an AoS copy
 // (x, y, z, original index: one 16-byte load per candidate).
 #include <type_traits>
 
