@@ -14,4 +14,16 @@ def loop(n, work):
         c.close()
     f1 = torch.cuda.mem_get_info()[0]
     print(f"{n} contexts, work={work}: delta {(f0 - f1) / 2**20:.1f} MiB")
+def loop_batch(n):
+    pairs = [(p["source"], p["target"])] * 5
+    f0 = torch.cuda.mem_get_info()[0]
+    for k in range(n):
+        os.environ["ICPK_BATCH_GROUP"] = "2"
+        c = binding.Context(0)
+        c.align_batch(pairs, max_iterations=3, fixed_iterations=1)  # slots, pools, set-up streams, events
+        c.align(max_iterations=8, threshold=1e-9) if False else None
+        c.close()
+    f1 = torch.cuda.mem_get_info()[0]
+    print(f"{n} contexts with a 5-pair batch each (groups of 2): delta {(f0 - f1) / 2**20:.1f} MiB")
 loop(50, False); loop(50, False); loop(50, True); loop(50, True); loop(200, True)
+loop_batch(10); loop_batch(10); loop_batch(30)
