@@ -13,6 +13,7 @@
 //      then frame 0 through icp::filterDepthImage: uint16[rows*cols];
 //      then icp::findGlobalKeyPointAssociations(source as key points, target as map, 0.1):
 //      int32 status, n_assoc, n_rejected; int32 pairs[2*n_assoc]; float errors[n_assoc]; int32 rejected[n_rejected]
+//      then frames 1 / 0 through a fresh icp::Tracker with filterFrames = true: int32 status, iterations; float T[16]
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -116,6 +117,16 @@ int main(int argc, char** argv) {
       }
       std::fwrite(errors.data(), 4, errors.size(), o);
       std::fwrite(rejected.data(), 4, rejected.size(), o);
+    }
+    if (nframes >= 2) {  // a fresh tracker with filterDepthImage inside the call (SLAM.cpp:229 + icp.cpp:38-71)
+      icp::Tracker flt(eng);
+      flt.params.fixed_iterations = 0;
+      flt.filterFrames = true;
+      float T[16];
+      const int32_t rc = flt.getTransformation(frames[1].data(), frames[0].data(), rows, cols, max_iter, thr, T);
+      const int32_t head[2] = {rc, flt.lastStats.iterations};
+      std::fwrite(head, 4, 2, o);
+      std::fwrite(T, 4, 16, o);
     }
   } catch (const std::exception& e) {
     std::fprintf(stderr, "%s\n", e.what());

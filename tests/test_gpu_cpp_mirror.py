@@ -96,4 +96,15 @@ def test_tracker_sequence_and_align(oracle):
     want = oracle.keypoint_associations(p["source"], p["target"], 0.1)
     assert krc == 0 and np.array_equal(pairs[:, 0], want[0]) and np.array_equal(pairs[:, 1], want[1])
     assert np.array_equal(errors.view(np.uint32), want[2].view(np.uint32)) and np.array_equal(rejected, want[3])
+    # icp::Tracker with filterFrames: filterDepthImage on both frames inside the call (icpk_backproject_pair)
+    rc, iters = struct.unpack_from("<2i", raw, off)
+    off += 8
+    T = np.frombuffer(raw, np.float32, 16, off).reshape(4, 4)
+    off += 4 * 16
+    I3, p5 = np.eye(3, dtype=np.float32), np.full(3, 5, np.float32)
+    tgt = oracle.transform_points(oracle.backproject(oracle.filter_depth_image(frames[0])), I3, p5)
+    src = oracle.transform_points(oracle.backproject(oracle.filter_depth_image(frames[1])), I3, p5)
+    o = oracle.align(src, tgt, max_iterations=max_iter, threshold=thr, solve=0, sum_order=1, threads=4)
+    assert rc == o["status"] and iters == o["iterations"]
+    assert np.linalg.norm(T.astype(np.float64) - o["T"].astype(np.float64)) < 1e-6
     assert off == len(raw)
