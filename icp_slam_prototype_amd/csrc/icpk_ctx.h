@@ -134,7 +134,7 @@ struct icpk_ctx {
   int t4_cap = 0;
   bool have_grid = false;  // grid matches tgt
   int grid_xdiv = 4;       // cells are this many times finer along x (ICPK_GRID_XDIV; measured best on config 2: 4)
-  float grid_ppc = 6.f;    // aimed-at targets per occupied cell (measured best on config 2: 6)
+  float grid_ppc = 8.f;    // aimed-at targets per occupied cell (ICPK_GRID_PPC; measured best on configs 2, 3 and the dense pair: 8)
   int grid_slices = 0;     // lanes per query (0 = by cloud size)
   std::string err;
   icpk_log_fn log_fn = nullptr;

@@ -99,7 +99,10 @@ void launch_tile_boxes(const float* x, const float* y, const float* z, int n, in
 void launch_decimate(const float* x, const float* y, const float* z, int n, int stride, float* ox, float* oy, float* oz,
                      int n_out_pad, hipStream_t s);
 // kernels_grid.hip: uniform grid over the target (ICPK_NN_GRID)
-constexpr int GRID_MAX_CELLS = 1 << 22;
+#ifndef ICPK_GRID_MAX_CELLS_LOG2
+#define ICPK_GRID_MAX_CELLS_LOG2 23  // 3 tables of 32 MB per context; 22 clipped the cell edge of the dense clouds
+#endif
+constexpr int GRID_MAX_CELLS = 1 << ICPK_GRID_MAX_CELLS_LOG2;
 constexpr int GRID_BOUNDS_PARTS = 256;  // partial boxes of the bounds pass (6 floats each)
 struct GridInfo {
   float lo[3];  // finite lower corner of the target

@@ -110,7 +110,10 @@ __device__ __forceinline__ void grid_info_body(const float* __restrict__ fbp, in
     ny = (int)(ext[1] / h) + 1;
     nz = (int)(ext[2] / h) + 1;
     if ((long long)nx * ny * nz <= GRID_MAX_CELLS) break;
-    h *= 1.26f;
+#ifndef ICPK_GRID_GROW
+#define ICPK_GRID_GROW 1.06f  // (1.26 left up to half of the table unused: a cell edge 20 % longer than necessary)
+#endif
+    h *= ICPK_GRID_GROW;
   }
   g->lo[0] = lo[0];
   g->lo[1] = lo[1];
