@@ -787,25 +787,7 @@ def test_many_iterations_uses_host_loop_and_matches(ctx, oracle):
 
 
 # ------------------------------------------------------------------- fuzzing --
-def _fuzz_cloud(rng, n, kind):
-    if kind == "uniform":
-        return rng.uniform(-3, 3, (3, n))
-    if kind == "clusters":
-        c = rng.uniform(-3, 3, (3, 12))
-        return c[:, rng.integers(0, 12, n)] + rng.normal(0, 0.02, (3, n))
-    if kind == "line":
-        t = rng.uniform(0, 1, n)
-        return np.stack([t * 4 - 2, 0.5 * t, np.full(n, 1.0)]) + rng.normal(0, 1e-4, (3, n))
-    if kind == "plane_lattice":
-        k = int(np.ceil(np.sqrt(n)))
-        u, v = np.meshgrid(np.arange(k), np.arange(k))
-        return np.stack([u.ravel()[:n] * 0.01, v.ravel()[:n] * 0.01, np.full(n, 2.0)])
-    if kind == "duplicates":
-        base = rng.uniform(-1, 1, (3, max(n // 7, 1)))
-        return base[:, rng.integers(0, base.shape[1], n)]
-    if kind == "tiny":
-        return rng.uniform(-1, 1, (3, n)) * 1e-6
-    return rng.uniform(-1, 1, (3, n)) * 1e4  # "huge"
+from soak_cases import fuzz_cloud as _fuzz_cloud  # noqa: E402  (shared with tools/soak_*.py)
 
 
 @pytest.mark.parametrize("seed", range(12))
