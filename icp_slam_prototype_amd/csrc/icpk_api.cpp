@@ -326,7 +326,7 @@ int enqueue_cell_order(icpk_ctx* ctx, bool with_points) {
 // scan-order copies of the queries and of their seed points (grid scan)
 int ensure_query_points(icpk_ctx* ctx, int nq) {
   if (nq <= ctx->qm4_cap) return ICPK_OK;
-  for (float4** pp : {&ctx->qm4, &ctx->sp_in, &ctx->sp_out}) {
+  for (float4** pp : {&ctx->qm4, &ctx->sp_in, &ctx->sp_out, &ctx->rec}) {
     if (*pp) ICPK_HIP(ctx, hipFree(*pp));
     *pp = nullptr;
   }
@@ -335,6 +335,7 @@ int ensure_query_points(icpk_ctx* ctx, int nq) {
   ICPK_HIP(ctx, hipMalloc((void**)&ctx->qm4, bytes));
   ICPK_HIP(ctx, hipMalloc((void**)&ctx->sp_in, bytes));
   ICPK_HIP(ctx, hipMalloc((void**)&ctx->sp_out, bytes));
+  ICPK_HIP(ctx, hipMalloc((void**)&ctx->rec, 2 * bytes));
   ctx->qm4_cap = round_up(nq, NN_TILE);
   ctx->grid_chain = false;
   return ICPK_OK;
@@ -446,6 +447,7 @@ GridSweepArgs grid_sweep_args(icpk_ctx* ctx, const NnArgs& a, const NnBoxes& bx)
   g.best = a.best;
   g.best_m = ctx->best_m;
   g.st = ctx->st_active;
+  g.rec = ctx->st_active ? ctx->rec : nullptr;  // inside a device loop K2 reads the records; planes / keys once at the end
   return g;
 }
 void after_grid_sweep(icpk_ctx* ctx) {
@@ -571,11 +573,15 @@ int enqueue_nn(icpk_ctx* ctx, int nn_mode, hipEvent_t ev0 = nullptr, hipEvent_t 
   return ICPK_OK;
 }
 
+// the records of the grid sweep just enqueued, if it was one of a device loop (then planes and keys are stale until
+// the loop's final unpack)
+const float4* loop_rec(const icpk_ctx* ctx) { return ctx->st_active && ctx->grid_chain ? ctx->rec : nullptr; }
+
 // enqueue K2 and the 160-byte read-back; caller synchronises
 int enqueue_reduce(icpk_ctx* ctx, float max_dist) {
   const int nq = ctx->src.n;
   launch_assoc_reduce(ctx->best, ctx->src.x(), ctx->src.y(), ctx->src.z(), nq, ctx->tgt.x(), ctx->tgt.y(), ctx->tgt.z(),
-                      ctx->have_grid ? ctx->o4 : nullptr, max_dist, ctx->st_active ? nullptr : ctx->idx, ctx->st_active ? nullptr : ctx->dist, ctx->partial,
+                      ctx->have_grid ? ctx->o4 : nullptr, loop_rec(ctx), max_dist, ctx->st_active ? nullptr : ctx->idx, ctx->st_active ? nullptr : ctx->dist, ctx->partial,
                       ctx->pcount, ctx->st_active ? nullptr : ctx->red_out,
                       ctx->st_active, ctx->st_active ? ctx->loop_nact : NSUM, ctx->stream);
   ICPK_HIP(ctx, hipGetLastError());
@@ -588,7 +594,7 @@ int enqueue_reduce(icpk_ctx* ctx, float max_dist) {
 // point-to-plane flavour of enqueue_reduce (K5)
 int enqueue_reduce_p2l(icpk_ctx* ctx, float max_dist) {
   launch_p2l_reduce(ctx->best, ctx->src.x(), ctx->src.y(), ctx->src.z(), ctx->src.n, ctx->tgt.x(), ctx->tgt.y(),
-                    ctx->tgt.z(), ctx->nrm.x(), ctx->nrm.y(), ctx->nrm.z(), max_dist, ctx->st_active ? nullptr : ctx->idx,
+                    ctx->tgt.z(), ctx->nrm.x(), ctx->nrm.y(), ctx->nrm.z(), loop_rec(ctx), max_dist, ctx->st_active ? nullptr : ctx->idx,
                     ctx->st_active ? nullptr : ctx->dist, ctx->partial,
                     ctx->pcount, ctx->st_active ? nullptr : ctx->red_out, ctx->st_active, ctx->stream);
   ICPK_HIP(ctx, hipGetLastError());
@@ -822,7 +828,7 @@ void icpk_destroy(icpk_ctx* ctx) {
                        ctx->batch_t0[1], ctx->batch_t1[0], ctx->batch_t1[1]})
     if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : ctx->events) (void)hipEventDestroy(e);
-  void* dev[] = {ctx->qcount, ctx->qstart, ctx->scan_bsum, ctx->qm4, ctx->sp_in, ctx->sp_out, ctx->grid_info, ctx->grid_bounds, ctx->cell_start, ctx->t4, ctx->o4, ctx->best_m, ctx->seed_m, ctx->st_pooled ? nullptr : (void*)ctx->st_dev, ctx->sorted.base, ctx->tkeys, ctx->tperm, ctx->qperm, ctx->bounds, ctx->sort_keys, ctx->sort_vals, ctx->sort_temp,
+  void* dev[] = {ctx->qcount, ctx->qstart, ctx->scan_bsum, ctx->qm4, ctx->sp_in, ctx->sp_out, ctx->rec, ctx->grid_info, ctx->grid_bounds, ctx->cell_start, ctx->t4, ctx->o4, ctx->best_m, ctx->seed_m, ctx->st_pooled ? nullptr : (void*)ctx->st_dev, ctx->sorted.base, ctx->tkeys, ctx->tperm, ctx->qperm, ctx->bounds, ctx->sort_keys, ctx->sort_vals, ctx->sort_temp,
                  ctx->nrm.base, ctx->boxes, ctx->dec.base, ctx->tgt.base, ctx->src0.base, ctx->src.base, ctx->best,      ctx->seed,     ctx->idx,
                  ctx->dist,     ctx->partial,   ctx->pcount,   ctx->red_out,   ctx->depth_dev, ctx->depth_flt, ctx->ks_buf, ctx->bp_counts};
   for (void* p : dev)
@@ -955,6 +961,11 @@ int icpk_get_associations(icpk_ctx* ctx, int32_t* idx_out, float* dist_out) {
   if (!ctx->have_assoc) return fail(ctx, ICPK_E_NOT_SET, "no nearest-neighbour sweep has run");
   ICPK_HIP(ctx, hipSetDevice(ctx->device));
   const int nq = ctx->src.n;
+  if (ctx->rec_pending) {  // a frame-batch slot after its lock-step loop
+    launch_grid_unpack(ctx->qm4, ctx->rec, nq, ctx->src.x(), ctx->src.y(), ctx->src.z(), ctx->best, ctx->stream);
+    ICPK_HIP(ctx, hipGetLastError());
+    ctx->rec_pending = false;
+  }
   if (nq > 0) {
     // K2 unpacks (distance, index) keys into the idx/dist planes
     int rc = enqueue_reduce(ctx, __builtin_inff());
@@ -1171,7 +1182,7 @@ static int align_device_loop(icpk_ctx* ctx, const icpk_params* p, float T_out[16
     }
     int r = enqueue_nn(ctx, p->nn_mode, e0, e1);
     if (r) return r;
-    ctx->best_of_sweep.push_back(ctx->best);
+    if (!loop_rec(ctx)) ctx->best_of_sweep.push_back(ctx->best);  // (grid sweeps keep ONE set of records: a sweep that runs at all supersedes the previous one)
     if (prof_all) {
       r = stamp(&ev_red);
       if (r) return r;
@@ -1205,6 +1216,8 @@ static int align_device_loop(icpk_ctx* ctx, const icpk_params* p, float T_out[16
     if (rc) return rc;
   }
   launch_loop_step(ctx->partial, ctx->pcount, B, nsum, ctx->st_dev, 1, ctx->stream);
+  if (loop_rec(ctx))  // the caller-order planes and keys the grid sweeps did not keep current, once
+    launch_grid_unpack(ctx->qm4, ctx->rec, ctx->src.n, ctx->src.x(), ctx->src.y(), ctx->src.z(), ctx->best, ctx->stream);
   ICPK_HIP(ctx, hipGetLastError());
   ICPK_HIP(ctx, hipMemcpyAsync(ctx->st_host, ctx->st_dev, sizeof(LoopState), hipMemcpyDeviceToHost, ctx->stream));
   ICPK_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1576,6 +1589,7 @@ int slot_setup_phase1(icpk_ctx* sl, const icpk_pair& pr, hipMemcpyKind kind) {
   if (sl->src.n <= 0) return ICPK_OK;  // an empty source takes the single-pair path
   sl->have_seed = false;
   sl->have_qperm = false;
+  sl->rec_pending = false;
   return ensure_assoc(sl, sl->src.n);
 }
 
@@ -1591,7 +1605,7 @@ int slot_setup_phase2(icpk_ctx* sl, const icpk_params* p, GridSweepArgs& first) 
   if (rc) return rc;
   first = grid_sweep_args(sl, a, bx);
   after_grid_sweep(sl);
-  sl->best_of_sweep.push_back(sl->best);
+  sl->rec_pending = true;  // planes / keys come from qm4 / rec on demand (icpk_get_associations)
   // (while the launches are being recorded the group's set-up event, recorded after the flush, takes its place)
   if (!setup_recorder()) ICPK_HIP(sl, hipEventRecord(sl->ready_ev, sl->stream));
   return ICPK_OK;
@@ -1607,6 +1621,7 @@ ReduceArgs slot_reduce_args(const icpk_ctx* sl) {
   r.ty = sl->tgt.y();
   r.tz = sl->tgt.z();
   r.o4 = sl->have_grid ? sl->o4 : nullptr;
+  r.rec = sl->rec;
   r.partial = sl->partial;
   r.pcount = sl->pcount;
   r.st = sl->st_dev;
@@ -1681,7 +1696,6 @@ int enqueue_group_loop(icpk_ctx* ctx, const icpk_params* p, const std::vector<ic
       }
       gb.p[k] = grid_sweep_args(sl, a, bx);
       after_grid_sweep(sl);
-      sl->best_of_sweep.push_back(sl->best);
       rb.p[k].best = sl->best;
     }
     src_ = sweep(i + 1, 0);  // icp.cpp:255, K3 fused

@@ -103,6 +103,8 @@ struct icpk_ctx {
   float4* qm4 = nullptr;     // queries in scan order (x, y, z, original index)
   float4* sp_in = nullptr;   // seeds as points, scan order: read by the next grid sweep
   float4* sp_out = nullptr;  // ... written by it
+  float4* rec = nullptr;     // device loop behind grid sweeps: caller-order records {(query, distance), (match, index)}, 2 float4 per query -- what K2 reads
+  bool rec_pending = false;  // frame-batch slot: the loop left planes / keys to be unpacked from qm4 / rec on demand (icpk_get_associations)
   int qm4_cap = 0;
   // frame-batch mode: child contexts (one per pair in flight; own stream for set-up work) --
   // owned by the parent, never handed out

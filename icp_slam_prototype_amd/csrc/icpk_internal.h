@@ -142,6 +142,7 @@ struct GridSweepArgs {
   nn_key_t* best;         // results, caller's order
   nn_key_t* best_m;       // results, scan order
   const LoopState* st;    // device-side loop state (K3 fused) or nullptr
+  float4* rec;            // device loop: caller-order records {(query, distance), (match, index)} INSTEAD of the planes / best / best_m stores; else nullptr
 };
 // frame-batch mode: up to BATCH_MAX independent pairs advance in lock step, one launch per
 // stage for the whole group (blockIdx.y / blockIdx.x = pair); arguments travel by value.
@@ -151,6 +152,8 @@ struct GridSweepBatch {
 };
 void launch_nn_grid(const GridSweepArgs& a, int slices, int expand, hipStream_t s);
 void launch_nn_grid_batch(const GridSweepBatch& b, int count, int slices, int expand, hipStream_t s);
+void launch_grid_unpack(const float4* qm4, const float4* rec, int nq, float* qx, float* qy, float* qz, nn_key_t* best,
+                        hipStream_t s);
 void launch_grid_query_points(const float* qx, const float* qy, const float* qz, const int* qperm, int nq,
                               const nn_key_t* seed_m, const float* ox, const float* oy, const float* oz, float4* qm4,
                               float4* sp, hipStream_t s);
@@ -221,8 +224,9 @@ void launch_reduce_final(const double* partial, const int* pcount, int nblocks, 
 // out == nullptr: only the per-block partials are produced (the device loop sums them
 // in launch_loop_step); stop: device-loop stop flags or nullptr
 // o4: the target as caller-order (x, y, z, 0) points or nullptr (then tx / ty / tz are gathered)
+// rec != nullptr (device loop behind a grid sweep): everything comes from the sweep's caller-order records instead
 void launch_assoc_reduce(const nn_key_t* best, const float* ax, const float* ay, const float* az, int nq,
-                         const float* tx, const float* ty, const float* tz, const float4* o4, float max_dist,
+                         const float* tx, const float* ty, const float* tz, const float4* o4, const float4* rec, float max_dist,
                          int32_t* idx_out, float* dist_out, double* partial, int* pcount, double* out, LoopState* st,
                          int nact, hipStream_t s);
 // one pair's arguments of K2 inside a device loop (no idx/dist unpacking, no final stage)
@@ -231,6 +235,7 @@ struct ReduceArgs {
   const float *ax, *ay, *az;
   const float *tx, *ty, *tz;
   const float4* o4;  // or nullptr
+  const float4* rec;  // the sweep's caller-order records
   double* partial;
   int* pcount;
   LoopState* st;
@@ -244,8 +249,8 @@ void launch_assoc_reduce_batch(const ReduceBatch& b, int count, float max_dist, 
 
 void launch_p2l_reduce(const nn_key_t* best, const float* ax, const float* ay, const float* az, int nq, const float* tx,
                        const float* ty, const float* tz, const float* nx, const float* ny, const float* nz,
-                       float max_dist, int32_t* idx_out, float* dist_out, double* partial, int* pcount, double* out,
-                       LoopState* st, hipStream_t s);
+                       const float4* rec, float max_dist, int32_t* idx_out, float* dist_out, double* partial, int* pcount,
+                       double* out, LoopState* st, hipStream_t s);
 
 // kernels_transform.hip
 void launch_transform(float* x, float* y, float* z, int n, const Rt& rt, hipStream_t s);

@@ -473,13 +473,17 @@ constexpr bool GRID_BALL_TRIM = true;
 // The sweep of ONE frame pair by workgroup `block` of its launch.  nn_grid_kernel runs it for
 // a single pair (arguments by value); nn_grid_batch_kernel runs blockIdx.y-many independent
 // pairs in lock step (frame-batch mode): same code, same results.
-template <int S, bool EXPAND>
+// REC (the sweeps of a device-side loop): the only caller-order output is rec[i] = {(moved query, distance), (matched
+// point, index)}, two adjacent 16-byte stores, which is all K2 reads; the caller's planes and keys (three 4-byte and one
+// 8-byte scattered store per query and sweep, each paying for a whole sector) are written ONCE after the loop by
+// grid_unpack_kernel.  Same values either way.
+template <int S, bool EXPAND, bool REC>
 __device__ __forceinline__ void nn_grid_body(
     float* __restrict__ qxp, float* __restrict__ qyp, float* __restrict__ qzp, const int nq, float4* __restrict__ qm4,
     const float4* __restrict__ t4, const int* __restrict__ cell_start, const GridInfo* __restrict__ gi,
     const float* __restrict__ oxp, const float* __restrict__ oyp, const float* __restrict__ ozp,
     const float4* __restrict__ sp_in, float4* __restrict__ sp_out, nn_key_t* __restrict__ best,
-    nn_key_t* __restrict__ best_m, const LoopState* __restrict__ st, const int block) {
+    nn_key_t* __restrict__ best_m, float4* __restrict__ rec, const LoopState* __restrict__ st, const int block) {
   // qm4: the queries in scan order (by grid cell), (x, y, z, original index) -- one coalesced
   // 16-byte load instead of the qperm -> coordinates chain; kept in step with the caller's
   // planes here.  sp_in / sp_out: the seed of every query as a point (x, y, z, target index) in
@@ -512,9 +516,11 @@ __device__ __forceinline__ void nn_grid_body(
     qz = (float)__builtin_fma((double)rt.R[8], pz, __builtin_fma((double)rt.R[7], py, (double)rt.R[6] * px)) + rt.t[2];
     if (live && slice == 0) {
       qm4[ip] = make_float4(qx, qy, qz, q4.w);
-      qxp[i] = qx;
-      qyp[i] = qy;
-      qzp[i] = qz;
+      if constexpr (!REC) {
+        qxp[i] = qx;
+        qyp[i] = qy;
+        qzp[i] = qz;
+      }
     }
     if (stop_after) return;  // < min_pairs fallback: the motion is applied, no further search
   }
@@ -720,17 +726,23 @@ __device__ __forceinline__ void nn_grid_body(
   // (the S lanes of a query already agree: the last pass ended with a merge)
   const nn_key_t key = ((nn_key_t)__float_as_uint(bd) << 32) | (nn_key_t)(unsigned)bj;
   if (live && slice == 0) {
-    best[i] = key;
-    best_m[ip] = key;
-    sp_out[ip] = make_float4(bx, by, bz, __int_as_float((int)(unsigned)(key & 0xffffffffu)));
+    const float4 m4 = make_float4(bx, by, bz, __int_as_float((int)(unsigned)(key & 0xffffffffu)));
+    if constexpr (REC) {
+      rec[2 * (size_t)i] = make_float4(qx, qy, qz, __uint_as_float((unsigned)(key >> 32)));
+      rec[2 * (size_t)i + 1] = m4;
+    } else {
+      best[i] = key;
+      best_m[ip] = key;
+    }
+    sp_out[ip] = m4;
   }
   GRID_STAMP(4);
 }
 
-template <int S, bool EXPAND>
+template <int S, bool EXPAND, bool REC>
 __global__ __launch_bounds__(ICPK_GRID_BLOCK) void nn_grid_kernel(const GridSweepArgs a) {
-  nn_grid_body<S, EXPAND>(a.qx, a.qy, a.qz, a.nq, a.qm4, a.t4, a.cell_start, a.gi, a.ox, a.oy, a.oz, a.sp_in, a.sp_out,
-                          a.best, a.best_m, a.st, blockIdx.x);
+  nn_grid_body<S, EXPAND, REC>(a.qx, a.qy, a.qz, a.nq, a.qm4, a.t4, a.cell_start, a.gi, a.ox, a.oy, a.oz, a.sp_in,
+                               a.sp_out, a.best, a.best_m, a.rec, a.st, blockIdx.x);
 }
 
 // frame-batch mode: blockIdx.y = pair.  The pairs of a group differ in size: workgroups beyond
@@ -739,15 +751,23 @@ template <int S, bool EXPAND>
 __global__ __launch_bounds__(ICPK_GRID_BLOCK) void nn_grid_batch_kernel(const GridSweepBatch b) {
   const GridSweepArgs& a = b.p[blockIdx.y];
   if ((long long)blockIdx.x * (64 / S) >= a.nq) return;
-  nn_grid_body<S, EXPAND>(a.qx, a.qy, a.qz, a.nq, a.qm4, a.t4, a.cell_start, a.gi, a.ox, a.oy, a.oz, a.sp_in, a.sp_out,
-                          a.best, a.best_m, a.st, blockIdx.x);
+  nn_grid_body<S, EXPAND, true>(a.qx, a.qy, a.qz, a.nq, a.qm4, a.t4, a.cell_start, a.gi, a.ox, a.oy, a.oz, a.sp_in,
+                                a.sp_out, a.best, a.best_m, a.rec, a.st, blockIdx.x);
 }
 
 static inline int grid_blocks(int nq, int slices) { return (nq + (64 / slices) - 1) / (64 / slices); }
 
 void launch_nn_grid(const GridSweepArgs& a, int slices, int expand, hipStream_t s) {
-#define ICPK_LAUNCH2(SL, EX) \
-  hipLaunchKernelGGL((nn_grid_kernel<SL, EX>), dim3(grid_blocks(a.nq, SL)), dim3(ICPK_GRID_BLOCK), 0, s, a)
+#define ICPK_LAUNCH3(SL, EX, RC) \
+  hipLaunchKernelGGL((nn_grid_kernel<SL, EX, RC>), dim3(grid_blocks(a.nq, SL)), dim3(ICPK_GRID_BLOCK), 0, s, a)
+#define ICPK_LAUNCH2(SL, EX)      \
+  do {                            \
+    if (a.rec) {                  \
+      ICPK_LAUNCH3(SL, EX, true);  \
+    } else {                      \
+      ICPK_LAUNCH3(SL, EX, false); \
+    }                             \
+  } while (0)
 #define ICPK_LAUNCH(SL)    \
   do {                     \
     if (expand) {          \
@@ -764,6 +784,7 @@ void launch_nn_grid(const GridSweepArgs& a, int slices, int expand, hipStream_t 
   }
 #undef ICPK_LAUNCH
 #undef ICPK_LAUNCH2
+#undef ICPK_LAUNCH3
 }
 
 void launch_nn_grid_batch(const GridSweepBatch& b, int count, int slices, int expand, hipStream_t s) {
@@ -811,6 +832,29 @@ void launch_grid_query_points(const float* qx, const float* qy, const float* qz,
   if (nq <= 0) return;
   hipLaunchKernelGGL(grid_query_points_kernel, dim3((nq + 255) / 256), dim3(256), 0, s, qx, qy, qz, qperm, nq, seed_m,
                      ox, oy, oz, qm4, sp);
+}
+
+// After a loop of REC sweeps: the caller-order views the sweeps did not keep current -- the moved source planes from
+// the scan-order queries (thread t as scan position) and the (distance, index) keys from the records (thread t as
+// query index).
+__global__ void grid_unpack_kernel(const float4* __restrict__ qm4, const float4* __restrict__ rec, int nq,
+                                   float* __restrict__ qx, float* __restrict__ qy, float* __restrict__ qz,
+                                   nn_key_t* __restrict__ best) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nq) return;
+  const float4 q = qm4[t];
+  const int i = __float_as_int(q.w);
+  qx[i] = q.x;
+  qy[i] = q.y;
+  qz[i] = q.z;
+  const float d = rec[2 * (size_t)t].w;
+  const float j = rec[2 * (size_t)t + 1].w;
+  best[t] = ((nn_key_t)__float_as_uint(d) << 32) | (nn_key_t)__float_as_uint(j);
+}
+void launch_grid_unpack(const float4* qm4, const float4* rec, int nq, float* qx, float* qy, float* qz, nn_key_t* best,
+                        hipStream_t s) {
+  if (nq <= 0) return;
+  hipLaunchKernelGGL(grid_unpack_kernel, dim3((nq + 255) / 256), dim3(256), 0, s, qm4, rec, nq, qx, qy, qz, best);
 }
 
 }  // namespace icpk

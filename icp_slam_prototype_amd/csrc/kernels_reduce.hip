@@ -39,9 +39,9 @@ template <int NACT>
 __device__ __forceinline__ void assoc_reduce_body(
     const nn_key_t* __restrict__ best, const float* __restrict__ ax, const float* __restrict__ ay,
     const float* __restrict__ az, int nq, const float* __restrict__ tx, const float* __restrict__ ty,
-    const float* __restrict__ tz, const float4* __restrict__ o4, float max_dist, int32_t* __restrict__ idx_out,
-    float* __restrict__ dist_out, double* __restrict__ partial, int* __restrict__ pcount, LoopState* __restrict__ st,
-    const int block, const int nblocks) {
+    const float* __restrict__ tz, const float4* __restrict__ o4, const float4* __restrict__ rec, float max_dist,
+    int32_t* __restrict__ idx_out, float* __restrict__ dist_out, double* __restrict__ partial, int* __restrict__ pcount,
+    LoopState* __restrict__ st, const int block, const int nblocks) {
   if (st) {
     if (st->done | st->stop_after_transform) return;
     if (block == 0 && threadIdx.x == 0) st->sweeps += 1;  // this sweep's associations are consumed
@@ -54,27 +54,8 @@ __device__ __forceinline__ void assoc_reduce_body(
   for (int s = 0; s < NACT; ++s) v[s] = 0.0;
   int cnt = 0;
 
-  for (int i = block * RED_THREADS + tid; i < nq; i += P) {
-    const nn_key_t key = best[i];
-    const float d = __uint_as_float((unsigned)(key >> 32));
-    const int j = (int)(unsigned)(key & 0xffffffffu);
-    if (idx_out) {  // (null in the device loop: icpk_get_associations unpacks on demand)
-      idx_out[i] = j;
-      dist_out[i] = d;
-    }
-    if (d < max_dist) {  // icp.cpp:553 (false for NaN)
-      const float a0 = ax[i], a1 = ay[i], a2 = az[i];
-      float b0, b1, b2;
-      if (o4) {  // (uniform) one 16-byte gather instead of three 4-byte ones
-        const float4 b = o4[j];
-        b0 = b.x;
-        b1 = b.y;
-        b2 = b.z;
-      } else {
-        b0 = tx[j];
-        b1 = ty[j];
-        b2 = tz[j];
-      }
+  // the accumulation of one accepted pair (a = moved query, b = its match, d = their distance)
+  auto add_pair = [&](float a0, float a1, float a2, float b0, float b1, float b2, float d) {
       const double da0 = a0, da1 = a1, da2 = a2, db0 = b0, db1 = b1, db2 = b2;
       v[0] += db0 * da0; v[1] += db0 * da1; v[2] += db0 * da2;
       v[3] += db1 * da0; v[4] += db1 * da1; v[5] += db1 * da2;
@@ -88,6 +69,36 @@ __device__ __forceinline__ void assoc_reduce_body(
         v[16] += db0; v[17] += db1; v[18] += db2;
       }
       ++cnt;
+  };
+  if (rec) {  // (uniform) behind a grid sweep of the device loop: one coalesced 32-byte record per query, no gather
+    for (int i = block * RED_THREADS + tid; i < nq; i += P) {
+      const float4 r0 = rec[2 * (size_t)i], r1 = rec[2 * (size_t)i + 1];
+      if (r0.w < max_dist) add_pair(r0.x, r0.y, r0.z, r1.x, r1.y, r1.z, r0.w);  // icp.cpp:553 (false for NaN)
+    }
+  } else {
+    for (int i = block * RED_THREADS + tid; i < nq; i += P) {
+      const nn_key_t key = best[i];
+      const float d = __uint_as_float((unsigned)(key >> 32));
+      const int j = (int)(unsigned)(key & 0xffffffffu);
+      if (idx_out) {  // (null in the device loop: icpk_get_associations unpacks on demand)
+        idx_out[i] = j;
+        dist_out[i] = d;
+      }
+      if (d < max_dist) {  // icp.cpp:553 (false for NaN)
+        const float a0 = ax[i], a1 = ay[i], a2 = az[i];
+        float b0, b1, b2;
+        if (o4) {  // (uniform) one 16-byte gather instead of three 4-byte ones
+          const float4 b = o4[j];
+          b0 = b.x;
+          b1 = b.y;
+          b2 = b.z;
+        } else {
+          b0 = tx[j];
+          b1 = ty[j];
+          b2 = tz[j];
+        }
+        add_pair(a0, a1, a2, b0, b1, b2, d);
+      }
     }
   }
 
@@ -112,9 +123,10 @@ template <int NACT>
 __global__ __launch_bounds__(RED_THREADS) void assoc_reduce_kernel(
     const nn_key_t* __restrict__ best, const float* __restrict__ ax, const float* __restrict__ ay,
     const float* __restrict__ az, int nq, const float* __restrict__ tx, const float* __restrict__ ty,
-    const float* __restrict__ tz, const float4* __restrict__ o4, float max_dist, int32_t* __restrict__ idx_out,
-    float* __restrict__ dist_out, double* __restrict__ partial, int* __restrict__ pcount, LoopState* __restrict__ st) {
-  assoc_reduce_body<NACT>(best, ax, ay, az, nq, tx, ty, tz, o4, max_dist, idx_out, dist_out, partial, pcount, st,
+    const float* __restrict__ tz, const float4* __restrict__ o4, const float4* __restrict__ rec, float max_dist,
+    int32_t* __restrict__ idx_out, float* __restrict__ dist_out, double* __restrict__ partial, int* __restrict__ pcount,
+    LoopState* __restrict__ st) {
+  assoc_reduce_body<NACT>(best, ax, ay, az, nq, tx, ty, tz, o4, rec, max_dist, idx_out, dist_out, partial, pcount, st,
                           blockIdx.x, gridDim.x);
 }
 
@@ -124,7 +136,7 @@ template <int NACT>
 __global__ __launch_bounds__(RED_THREADS) void assoc_reduce_batch_kernel(const ReduceBatch b, float max_dist) {
   const ReduceArgs& a = b.p[blockIdx.y];
   if ((int)blockIdx.x >= a.nblocks) return;
-  assoc_reduce_body<NACT>(a.best, a.ax, a.ay, a.az, a.nq, a.tx, a.ty, a.tz, a.o4, max_dist, nullptr, nullptr,
+  assoc_reduce_body<NACT>(a.best, a.ax, a.ay, a.az, a.nq, a.tx, a.ty, a.tz, a.o4, a.rec, max_dist, nullptr, nullptr,
                           a.partial, a.pcount, a.st, blockIdx.x, a.nblocks);
 }
 
@@ -136,8 +148,8 @@ __global__ __launch_bounds__(RED_THREADS) void p2l_reduce_kernel(
     const nn_key_t* __restrict__ best, const float* __restrict__ ax, const float* __restrict__ ay,
     const float* __restrict__ az, int nq, const float* __restrict__ tx, const float* __restrict__ ty,
     const float* __restrict__ tz, const float* __restrict__ nxp, const float* __restrict__ nyp,
-    const float* __restrict__ nzp, float max_dist, int32_t* __restrict__ idx_out, float* __restrict__ dist_out,
-    double* __restrict__ partial, int* __restrict__ pcount, LoopState* __restrict__ st) {
+    const float* __restrict__ nzp, const float4* __restrict__ rec, float max_dist, int32_t* __restrict__ idx_out,
+    float* __restrict__ dist_out, double* __restrict__ partial, int* __restrict__ pcount, LoopState* __restrict__ st) {
   if (st) {
     if (st->done | st->stop_after_transform) return;
     if (blockIdx.x == 0 && threadIdx.x == 0) st->sweeps += 1;
@@ -149,18 +161,28 @@ __global__ __launch_bounds__(RED_THREADS) void p2l_reduce_kernel(
   for (int s = 0; s < NP2L; ++s) v[s] = 0.0;
   int cnt = 0;
   for (int i = blockIdx.x * RED_THREADS + tid; i < nq; i += P) {
-    const nn_key_t key = best[i];
-    const float d = __uint_as_float((unsigned)(key >> 32));
-    const int j = (int)(unsigned)(key & 0xffffffffu);
-    if (idx_out) {  // (null in the device loop: icpk_get_associations unpacks on demand)
-      idx_out[i] = j;
-      dist_out[i] = d;
+    float d, a0, a1, a2, b0 = 0.f, b1 = 0.f, b2 = 0.f;
+    int j;
+    if (rec) {  // (uniform) behind a grid sweep of the device loop: query, match and distance in one 32-byte record
+      const float4 r0 = rec[2 * (size_t)i], r1 = rec[2 * (size_t)i + 1];
+      a0 = r0.x, a1 = r0.y, a2 = r0.z, d = r0.w;
+      b0 = r1.x, b1 = r1.y, b2 = r1.z, j = __float_as_int(r1.w);
+    } else {
+      const nn_key_t key = best[i];
+      d = __uint_as_float((unsigned)(key >> 32));
+      j = (int)(unsigned)(key & 0xffffffffu);
+      if (idx_out) {  // (null in the device loop: icpk_get_associations unpacks on demand)
+        idx_out[i] = j;
+        dist_out[i] = d;
+      }
+      a0 = ax[i], a1 = ay[i], a2 = az[i];
     }
     if (d < max_dist) {
       const double n0 = nxp[j], n1 = nyp[j], n2 = nzp[j];
       if (!(n0 == 0.0 && n1 == 0.0 && n2 == 0.0)) {
-        const double p0 = ax[i], p1 = ay[i], p2 = az[i];
-        const double q0 = tx[j], q1 = ty[j], q2 = tz[j];
+        if (!rec) b0 = tx[j], b1 = ty[j], b2 = tz[j];
+        const double p0 = a0, p1 = a1, p2 = a2;
+        const double q0 = b0, q1 = b1, q2 = b2;
         double J[6];
         J[0] = p1 * n2 - p2 * n1;
         J[1] = p2 * n0 - p0 * n2;
@@ -195,25 +217,25 @@ __global__ __launch_bounds__(RED_THREADS) void p2l_reduce_kernel(
 
 void launch_p2l_reduce(const nn_key_t* best, const float* ax, const float* ay, const float* az, int nq, const float* tx,
                        const float* ty, const float* tz, const float* nx, const float* ny, const float* nz,
-                       float max_dist, int32_t* idx_out, float* dist_out, double* partial, int* pcount, double* out,
-                       LoopState* st, hipStream_t s) {
+                       const float4* rec, float max_dist, int32_t* idx_out, float* dist_out, double* partial, int* pcount,
+                       double* out, LoopState* st, hipStream_t s) {
   const int B = red_blocks(nq);
   hipLaunchKernelGGL(p2l_reduce_kernel, dim3(B), dim3(RED_THREADS), 0, s, best, ax, ay, az, nq, tx, ty, tz, nx, ny, nz,
-                     max_dist, idx_out, dist_out, partial, pcount, st);
+                     rec, max_dist, idx_out, dist_out, partial, pcount, st);
   if (out) launch_reduce_final(partial, pcount, B, NP2L, out, s);
 }
 
 void launch_assoc_reduce(const nn_key_t* best, const float* ax, const float* ay, const float* az, int nq,
-                         const float* tx, const float* ty, const float* tz, const float4* o4, float max_dist,
-                         int32_t* idx_out, float* dist_out, double* partial, int* pcount, double* out, LoopState* st,
-                         int nact, hipStream_t s) {
+                         const float* tx, const float* ty, const float* tz, const float4* o4, const float4* rec,
+                         float max_dist, int32_t* idx_out, float* dist_out, double* partial, int* pcount, double* out,
+                         LoopState* st, int nact, hipStream_t s) {
   const int B = red_blocks(nq);
   if (nact == NSUM_REF && !out)
     hipLaunchKernelGGL(assoc_reduce_kernel<NSUM_REF>, dim3(B), dim3(RED_THREADS), 0, s, best, ax, ay, az, nq, tx, ty, tz,
-                       o4, max_dist, idx_out, dist_out, partial, pcount, st);
+                       o4, rec, max_dist, idx_out, dist_out, partial, pcount, st);
   else
     hipLaunchKernelGGL(assoc_reduce_kernel<NSUM>, dim3(B), dim3(RED_THREADS), 0, s, best, ax, ay, az, nq, tx, ty, tz, o4,
-                       max_dist, idx_out, dist_out, partial, pcount, st);
+                       rec, max_dist, idx_out, dist_out, partial, pcount, st);
   if (out) launch_reduce_final(partial, pcount, B, NSUM, out, s);
 }
 
