@@ -184,6 +184,7 @@ struct LoopState {
   // being written by an alignment that was abandoned on an error are never taken for this one's.
   int* progress;
   Rt rt;                     // transform to apply in this iteration
+  double Rd[9];              // rt.R widened (exact) by the step: the sweeps' fused K3 takes the rotation as float64 scalars
   float Trot[9];             // icp.cpp:227-233
   float offset[3];           // icp.cpp:240
   double Tk[12];             // accumulated [R|t] (Kabsch / point-to-plane)

@@ -401,8 +401,8 @@ void launch_grid_info_batch(const SetupBatchOf<InfoArgs>& b, int count, hipStrea
 // an edge cell is unbounded.  For a target of row (iy, iz) therefore
 //   (q_x - t_x)^2 <= B^2 - gap_y^2 - gap_z^2,
 // evaluated with B^2 rounded up and the gaps' squares rounded down: negative -> the row holds nothing that
-// matters; else the x cells come from q_x -/+ (sqrt(.) (1 + 2^-20) + |q_x| 2^-21 + 2^-74) exactly as the
-// cube's do.  Candidates per query on config 2: 32 -> see DESIGN.md.
+// matters; else the x cells come from q_x -/+ (sqrt(.) (1 + 2^-19) + |q_x| 2^-21 + 2^-74) as the cube's do (the
+// root by the bare v_sqrt_f32, <= 1 ulp low, of an argument clamped to >= 2^-100; only for 2^-40 <= B <= 2^60).  Candidates per query on config 2: 32 -> see DESIGN.md.
 // pair_dist of nn_device.h from the differences the fp32 filter already holds, one conversion at a time (the
 // same operations, hence the same bits; fewer float64 temporaries alive at the kernel's register peak)
 __device__ __forceinline__ float pair_dist_seq(float dx, float dy, float dz) {
@@ -509,11 +509,14 @@ __device__ __forceinline__ void nn_grid_body(
   const int i = __float_as_int(q4.w);
   float qx = q4.x, qy = q4.y, qz = q4.z;
   if (apply_rt) {  // pointcloud.cpp:321-359: p <- fl32(fl32(R p) + t)
-    const Rt rt = st->rt;
+    // (the rotation as the float64 values the step kernel widened once: wave-uniform scalar operands, no per-lane
+    // conversions; the same numbers, hence the same bits)
+    const double* __restrict__ Rd = st->Rd;
+    const float t0 = st->rt.t[0], t1 = st->rt.t[1], t2 = st->rt.t[2];
     const double px = qx, py = qy, pz = qz;
-    qx = (float)__builtin_fma((double)rt.R[2], pz, __builtin_fma((double)rt.R[1], py, (double)rt.R[0] * px)) + rt.t[0];
-    qy = (float)__builtin_fma((double)rt.R[5], pz, __builtin_fma((double)rt.R[4], py, (double)rt.R[3] * px)) + rt.t[1];
-    qz = (float)__builtin_fma((double)rt.R[8], pz, __builtin_fma((double)rt.R[7], py, (double)rt.R[6] * px)) + rt.t[2];
+    qx = (float)__builtin_fma(Rd[2], pz, __builtin_fma(Rd[1], py, Rd[0] * px)) + t0;
+    qy = (float)__builtin_fma(Rd[5], pz, __builtin_fma(Rd[4], py, Rd[3] * px)) + t1;
+    qz = (float)__builtin_fma(Rd[8], pz, __builtin_fma(Rd[7], py, Rd[6] * px)) + t2;
     if (live && slice == 0) {
       qm4[ip] = make_float4(qx, qy, qz, q4.w);
       if constexpr (!REC) {
@@ -539,6 +542,7 @@ __device__ __forceinline__ void nn_grid_body(
 
   // a NaN best distance can never be replaced (d < NaN and d == NaN are false): no scan
   const bool scan = live && bd == bd;
+  bool own = slice == 0;  // this lane's (bx, by, bz) is the point of the group's agreed key (see share)
   const GridInfo g = *gi;
   // The S lanes of a query share the candidates of a cell box evenly.  Rows are taken S at a
   // time: lane k fetches the range of row k, a prefix sum over the S lanes numbers the
@@ -560,8 +564,17 @@ __device__ __forceinline__ void nn_grid_body(
       const int row = r0 + slice;
       int s0 = 0, len = 0;
       if (row < nrows) {
-        const int rz = row / nyr;
-        const int ry = row - rz * nyr;
+        // row = rz * nyr + ry without an integer division (~30 instructions): the float quotient is within 1 of the
+        // true one (row < 2^20 rows, relative error of rcp and product < 2^-21), two compare-and-fix steps make it exact
+        int rz = (int)((float)row * __builtin_amdgcn_rcpf((float)nyr));
+        int ry = row - rz * nyr;
+        if (ry < 0) {
+          rz -= 1;
+          ry += nyr;
+        } else if (ry >= nyr) {
+          rz += 1;
+          ry -= nyr;
+        }
         const int iy = y0 + ry, iz = z0 + rz;
         const int base = (iz * g.ny + iy) * g.nx;
         int xa = x0, xb = x1;
@@ -570,7 +583,7 @@ __device__ __forceinline__ void nn_grid_body(
         // finite float for the arithmetic to mean anything -- else the cube alone.  (Everything is recomputed
         // per chunk: bd may have improved, and nothing stays live across the candidate loop.)
         const float B = __builtin_fmaf(bd, 1.0f + 0x1p-19f, 0x1p-74f);
-        if (GRID_BALL_TRIM && B >= 0x1p-60f && B <= 0x1p60f) {
+        if (GRID_BALL_TRIM && B >= 0x1p-40f && B <= 0x1p60f) {
           const float B2 = B * B * (1.0f + 0x1p-22f);
           float qx_ = qx, qy_ = qy, qz_ = qz;  // (opaque copies: keep the loop-invariant terms from being hoisted into registers)
           asm volatile("" : "+v"(qx_), "+v"(qy_), "+v"(qz_));
@@ -583,7 +596,10 @@ __device__ __forceinline__ void nn_grid_body(
           if (dx2 < 0.f) {
             xb = xa - 1;  // no target of this row can tie or beat the current best
           } else {
-            const float rrx = __builtin_fmaf(__builtin_sqrtf(dx2), 1.0f + 0x1p-20f,
+            // an UPPER bound of the root is all that is wanted: the bare v_sqrt_f32 (within 1 ulp for a normal argument;
+            // the correctly rounded sqrtf costs 17 instructions) of an argument kept normal (B >= 2^-40, so 2^-50 is
+            // far below anything that matters), times 1 + 2^-19 instead of 1 + 2^-20
+            const float rrx = __builtin_fmaf(__builtin_amdgcn_sqrtf(__builtin_fmaxf(dx2, 0x1p-100f)), 1.0f + 0x1p-19f,
                                              __builtin_fmaf(__builtin_fabsf(qx_), 0x1p-21f, 0x1p-74f));
             xa = max(xa, grid_cell(qx_ - rrx, g.lo[0], g.inv_hx, g.nx));
             xb = min(xb, grid_cell(qx_ + rrx, g.lo[0], g.inv_hx, g.nx));
@@ -653,6 +669,7 @@ __device__ __forceinline__ void nn_grid_body(
             by = up ? v[k].y : by;
             bz = up ? v[k].z : bz;
             T = up ? filt_threshold(d) : T;
+            own = own | up;
           }
         }
       }
@@ -666,28 +683,28 @@ __device__ __forceinline__ void nn_grid_body(
   // NN distance, not to the seed's.  EXPAND = false (seeds are the previous sweep's matches):
   // one pass over the whole cube of the seed distance -- fewer round trips than two passes,
   // and a leaner kernel.
-  auto share = [&]() {  // the S lanes of a query agree on the best (distance, index, point) so far
+  // The S lanes of a query agree on the best (distance, index) so far: two min-reductions over the group --
+  // distance bits (non-negative floats order like their bit patterns), then the index among the lanes that hold
+  // that distance.  The matched POINT does not travel: `own` marks the one lane whose (bx, by, bz) belong to the
+  // agreed key -- the lane that found it, or slice 0 for the seed all S lanes start from -- and that lane stores the
+  // result.  (There always is one: a lane holds a key either as its own find or as a copy of a lane that still holds
+  // it, unless that lane has found something better since, and then the better key is the agreed one.  Finds are
+  // unique to a lane: the S lanes walk disjoint candidates and skip the current best itself.)
+  auto group_min = [&](unsigned v) -> unsigned {  // all-reduce over the S adjacent lanes (any pairing pattern does for a minimum)
+    if constexpr (S >= 2) v = min(v, (unsigned)dpp_mov<0xB1>((int)v));   // quad_perm [1,0,3,2]
+    if constexpr (S >= 4) v = min(v, (unsigned)dpp_mov<0x4E>((int)v));   // quad_perm [2,3,0,1]
+    if constexpr (S >= 8) v = min(v, (unsigned)dpp_mov<0x141>((int)v));  // row_half_mirror: lane i <-> 7 - i, i.e. the other quad
+    return v;
+  };
+  auto share = [&]() {
     if (S > 1) {
-      nn_key_t k2 = ((nn_key_t)__float_as_uint(bd) << 32) | (nn_key_t)(unsigned)bj;
-      auto step = [&](auto mc) {  // butterfly: the winner's point travels with its key
-        constexpr int M = decltype(mc)::value;
-        const nn_key_t o = ((nn_key_t)(unsigned)xor_lane<M>((int)(unsigned)(k2 >> 32)) << 32) |
-                           (nn_key_t)(unsigned)xor_lane<M>((int)(unsigned)(k2 & 0xffffffffu));
-        const float ox_ = __int_as_float(xor_lane<M>(__float_as_int(bx)));
-        const float oy_ = __int_as_float(xor_lane<M>(__float_as_int(by)));
-        const float oz_ = __int_as_float(xor_lane<M>(__float_as_int(bz)));
-        const bool take = o < k2;
-        k2 = take ? o : k2;
-        bx = take ? ox_ : bx;
-        by = take ? oy_ : by;
-        bz = take ? oz_ : bz;
-      };
-      if constexpr (S >= 2) step(std::integral_constant<int, 1>{});
-      if constexpr (S >= 4) step(std::integral_constant<int, 2>{});
-      if constexpr (S >= 8) step(std::integral_constant<int, 4>{});
-      if (scan) {  // (a NaN distance is not ordered by its bits; such lanes never scan)
-        bd = __uint_as_float((unsigned)(k2 >> 32));
-        bj = (int)(unsigned)(k2 & 0xffffffffu);
+      const unsigned db = __float_as_uint(bd);
+      const unsigned dm = group_min(db);
+      const unsigned jm = group_min(db == dm ? (unsigned)bj : 0xffffffffu);
+      if (scan) {  // (a NaN distance is not ordered by its bits; such lanes never scan, and the S lanes of a query scan or do not together)
+        own = own && db == dm && (unsigned)bj == jm;
+        bd = __uint_as_float(dm);
+        bj = (int)jm;
         T = filt_threshold(bd);
       }
     }
@@ -723,9 +740,10 @@ __device__ __forceinline__ void nn_grid_body(
   }
 
   GRID_STAMP(3);
-  // (the S lanes of a query already agree: the last pass ended with a merge)
+  // (the S lanes of a query already agree on the key: the last pass ended with a merge; the lane that owns the
+  // matched point stores)
   const nn_key_t key = ((nn_key_t)__float_as_uint(bd) << 32) | (nn_key_t)(unsigned)bj;
-  if (live && slice == 0) {
+  if (live && own) {
     const float4 m4 = make_float4(bx, by, bz, __int_as_float((int)(unsigned)(key & 0xffffffffu)));
     if constexpr (REC) {
       rec[2 * (size_t)i] = make_float4(qx, qy, qz, __uint_as_float((unsigned)(key >> 32)));

@@ -150,6 +150,7 @@ __device__ __forceinline__ void loop_step_body(const double* __restrict__ partia
       st->rt.t[k] = st->last_translation[k];
       st->offset[k] = -st->last_translation[k];
     }
+    for (int k = 0; k < 9; ++k) st->Rd[k] = (double)st->rt.R[k];
     st->status = 1;  // ICPK_W_TOO_FEW_PAIRS
     st->stop_after_transform = 1;
     publish_progress(st);
@@ -208,6 +209,7 @@ __device__ __forceinline__ void loop_step_body(const double* __restrict__ partia
     compose_rt(Rrec, trec, st->Tk);
   }
   STEP_STAMP(i, 3);
+  for (int k = 0; k < 9; ++k) st->Rd[k] = (double)st->rt.R[k];
   for (int k = 0; k < 9; ++k) st->trace_R[9 * i + k] = Rrec[k];
   for (int k = 0; k < 3; ++k) st->trace_t[3 * i + k] = trec[k];
   st->iterations = i + 1;  // icp.cpp:257 (the sweep that follows is already enqueued)
