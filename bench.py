@@ -571,28 +571,43 @@ def tracker_path(gpu_index):
     ctx = binding.Context(gpu_index)
     camR, camP = np.eye(3, dtype=np.float32), np.full(3, 5, np.float32)
     res = {}
-    for filt in (False, True):
-        def pair(prev, cur):
-            ctx.backproject_pair(cur, prev, R=camR, t=camP, filter=filt)  # icp.cpp:38-71 in one call
+    # resident: the previous frame is the one the context received as `data` last time (SLAM.cpp:305 hands it back):
+    # it stays on the device, one 614 KB upload per call instead of two -- icp::Tracker's getTransformation(data, nullptr, ...)
+    for key, filt, resident in (("plain", False, True), ("with_filterDepthImage", True, True), ("both_frames_uploaded", False, False)):
+        stage = {"backproject_pair": 0.0, "align": 0.0, "get_trace": 0.0}
+
+        def pair(prev, cur, first):
+            t0 = time.perf_counter()
+            ctx.backproject_pair(cur, prev if (first or not resident) else None, R=camR, t=camP, filter=filt)  # icp.cpp:38-71 in one call
+            t1 = time.perf_counter()
             T, st, rc = ctx.align(max_iterations=16, threshold=1e-4)
+            t2 = time.perf_counter()
             ctx.get_trace(16)
+            t3 = time.perf_counter()
+            stage["backproject_pair"] += t1 - t0
+            stage["align"] += t2 - t1
+            stage["get_trace"] += t3 - t2
             return st
 
         for i in range(1, len(frames)):
-            pair(frames[i - 1], frames[i])
+            pair(frames[i - 1], frames[i], i == 1)
+        for k in stage:
+            stage[k] = 0.0
         t0 = time.perf_counter()
         n = its = 0
         for _ in range(4):
             for i in range(1, len(frames)):
-                its += pair(frames[i - 1], frames[i]).iterations
+                # (the sequence wraps around: frame 1 follows frame 5 only through an explicit `previous`)
+                its += pair(frames[i - 1], frames[i], i == 1).iterations
                 n += 1
         dt = time.perf_counter() - t0
-        res["with_filterDepthImage" if filt else "plain"] = {
-            "frame_pairs_per_s": n / dt, "ms_per_pair": dt / n * 1e3, "mean_iterations": its / n,
-            "points": [ctx.source_size, ctx.target_size]}
+        res[key] = {"frame_pairs_per_s": n / dt, "ms_per_pair": dt / n * 1e3, "mean_iterations": its / n,
+                    "points": [ctx.source_size, ctx.target_size],
+                    "host_ms_per_call": {k: round(v / n * 1e3, 4) for k, v in stage.items()}}
     ctx.close()
     res["workload"] = ("6 synthetic 640x480 frames (30 % valid, camera drifting 0.5 degree / 1 cm per frame), consecutive pairs, "
-                       "threshold exit; host depth images in, 4x4 + trace out")
+                       "threshold exit; host depth images in, 4x4 + trace out; plain / with_filterDepthImage: the previous frame "
+                       "stays on the device (one upload per call); both_frames_uploaded: as round 2 measured it")
     return res
 
 

@@ -439,8 +439,9 @@ class Context:
         """icp.cpp:38-71 in one call: both frames back-projected (filtered first if filter), posed by (R, t),
         the posed source committed.  Returns (n_source, n_target)."""
         ds = np.ascontiguousarray(depth_source, np.uint16)
-        dt = np.ascontiguousarray(depth_target, np.uint16)
-        if ds.shape != dt.shape or ds.ndim != 2:
+        # depth_target None: the frame this context received as depth_source last time, still on the device (SLAM.cpp:305)
+        dt = None if depth_target is None else np.ascontiguousarray(depth_target, np.uint16)
+        if ds.ndim != 2 or (dt is not None and ds.shape != dt.shape):
             raise ValueError("two depth images of the same rows x cols shape expected")
         rows, cols = ds.shape
         off = None if offset is None else _f(offset)
@@ -449,7 +450,7 @@ class Context:
         ns, nt = C.c_int32(-1), C.c_int32(-1)
         u16 = C.POINTER(C.c_uint16)
         self._chk(self._lib.icpk_backproject_pair(
-            self._h, ds.ctypes.data_as(u16), dt.ctypes.data_as(u16), rows, cols, fx, cx, None if off is None else _fp(off),
+            self._h, ds.ctypes.data_as(u16), None if dt is None else dt.ctypes.data_as(u16), rows, cols, fx, cx, None if off is None else _fp(off),
             None if Rm is None else _fp(Rm), None if tv is None else _fp(tv), int(bool(filter)), int(max_d), int(min_d),
             int(bool(morph)), int(anchor[0]), int(anchor[1]), C.byref(ns), C.byref(nt)))
         return ns.value, nt.value

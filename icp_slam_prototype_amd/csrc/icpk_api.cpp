@@ -1959,6 +1959,7 @@ static int ensure_depth_buffers(icpk_ctx* ctx, int count, int ints) {
     if (ctx->depth_flt) ICPK_HIP(ctx, hipFree(ctx->depth_flt));
     ctx->depth_dev = ctx->depth_flt = nullptr;
     ctx->depth_cap = 0;
+    ctx->frame_slot = -1;
     ICPK_HIP(ctx, hipMalloc((void**)&ctx->depth_dev, (size_t)count * sizeof(uint16_t)));
     ICPK_HIP(ctx, hipMalloc((void**)&ctx->depth_flt, (size_t)count * sizeof(uint16_t)));
     ctx->depth_cap = count;
@@ -1987,6 +1988,7 @@ static int backproject_impl(icpk_ctx* ctx, const uint16_t* depth, int32_t rows, 
   Cloud& c = which == 0 ? ctx->src0 : ctx->tgt;
   rc = ensure_cloud(ctx, c, npix);  // worst case: every pixel valid
   if (rc) return rc;
+  ctx->frame_slot = -1;  // (the image buffers are shared with icpk_backproject_pair's resident frame)
   ICPK_HIP(ctx, hipMemcpyAsync(ctx->depth_dev, depth, (size_t)npix * sizeof(uint16_t), hipMemcpyHostToDevice, ctx->stream));
   const uint16_t* dimg = ctx->depth_dev;
   if (flt) {  // SLAM.cpp:229,553-574: the frame is filtered before it is back-projected
@@ -2039,7 +2041,7 @@ int icpk_backproject_pair(icpk_ctx* ctx, const uint16_t* depth_source, const uin
                           int32_t cols, float fx, float cx, const float offset[3], const float R[9], const float t[3],
                           int32_t filter, int32_t max_d, int32_t min_d, int32_t morph, int32_t anchor_x, int32_t anchor_y,
                           int32_t* n_source, int32_t* n_target) {
-  if (!ctx || !depth_source || !depth_target || rows <= 0 || cols <= 0 || (int64_t)rows * cols > (1 << 27) || (!R != !t))
+  if (!ctx || !depth_source || rows <= 0 || cols <= 0 || (int64_t)rows * cols > (1 << 27) || (!R != !t))
     return ICPK_E_ARG;
   int ax = anchor_x, ay = anchor_y;
   int rc = filter ? check_filter(ctx, morph, ax, ay) : ICPK_OK;
@@ -2048,26 +2050,43 @@ int icpk_backproject_pair(icpk_ctx* ctx, const uint16_t* depth_source, const uin
   const int npix = rows * cols;
   const int nblocks = (npix + 1023) / 1024;
   const int per_image = nblocks + 2;
+  const int fset[6] = {filter != 0, max_d, min_d, morph != 0, ax, ay};
+  // depth_target == NULL: the previous frame is the one this context saw as `depth_source` last time (SLAM.cpp:305,
+  // previous = filtered.clone()): its image -- and its filtered copy -- are still on the device
+  const bool resident = depth_target == nullptr;
+  if (resident && (ctx->frame_slot < 0 || ctx->frame_rows != rows || ctx->frame_cols != cols || 2 * npix > ctx->depth_cap))
+    return icpk_host_fail(ctx, ICPK_E_NOT_SET, "no resident previous frame of this size (pass depth_target)");
+  if (!resident && 2 * npix > ctx->depth_cap) ctx->frame_slot = -1;  // (the buffers are about to be replaced)
   rc = ensure_depth_buffers(ctx, 2 * npix, 2 * per_image + 2);
   if (rc) return rc;
   for (Cloud* c : {&ctx->src0, &ctx->src, &ctx->tgt}) {
     rc = ensure_cloud(ctx, *c, npix);  // worst case: every pixel valid
     if (rc) return rc;
   }
+  // two image slots; the new frame goes where the resident one is not
+  const int tslot = resident ? ctx->frame_slot : 1;
+  const int sslot = 1 - tslot;
+  uint16_t* const raw_s = ctx->depth_dev + (size_t)sslot * npix;
+  uint16_t* const raw_t = ctx->depth_dev + (size_t)tslot * npix;
+  uint16_t* const flt_s = ctx->depth_flt + (size_t)sslot * npix;
+  uint16_t* const flt_t = ctx->depth_flt + (size_t)tslot * npix;
   const size_t bytes = (size_t)npix * sizeof(uint16_t);
-  ICPK_HIP(ctx, hipMemcpyAsync(ctx->depth_dev, depth_source, bytes, hipMemcpyHostToDevice, ctx->stream));
-  ICPK_HIP(ctx, hipMemcpyAsync(ctx->depth_dev + npix, depth_target, bytes, hipMemcpyHostToDevice, ctx->stream));
-  const uint16_t* img = ctx->depth_dev;
+  ctx->frame_slot = -1;  // (nothing is resident until this call has enqueued everything)
+  ICPK_HIP(ctx, hipMemcpyAsync(raw_s, depth_source, bytes, hipMemcpyHostToDevice, ctx->stream));
+  if (!resident) ICPK_HIP(ctx, hipMemcpyAsync(raw_t, depth_target, bytes, hipMemcpyHostToDevice, ctx->stream));
+  const uint16_t *img_s = raw_s, *img_t = raw_t;
   if (filter) {  // SLAM.cpp:229,553-574: the frames are filtered before they are back-projected
-    for (int k = 0; k < 2; ++k)
-      launch_depth_filter(ctx->depth_dev + (size_t)k * npix, ctx->depth_flt + (size_t)k * npix, rows, cols, min_d, max_d, ax,
-                          ay, morph != 0, ctx->stream);
-    img = ctx->depth_flt;
+    launch_depth_filter(raw_s, flt_s, rows, cols, min_d, max_d, ax, ay, morph != 0, ctx->stream);
+    // (the resident frame's filtered copy is reused when it was made with the same settings)
+    if (!resident || std::memcmp(fset, ctx->frame_filter, sizeof(fset)) != 0)
+      launch_depth_filter(raw_t, flt_t, rows, cols, min_d, max_d, ax, ay, morph != 0, ctx->stream);
+    img_s = flt_s;
+    img_t = flt_t;
   }
   BpPair b;
-  b.im[0] = BpImage{img, ctx->src0.x(), ctx->src0.y(), ctx->src0.z(), ctx->src.x(), ctx->src.y(), ctx->src.z(),
+  b.im[0] = BpImage{img_s, ctx->src0.x(), ctx->src0.y(), ctx->src0.z(), ctx->src.x(), ctx->src.y(), ctx->src.z(),
                     ctx->bp_counts, 0.f};
-  b.im[1] = BpImage{img + npix, ctx->tgt.x(), ctx->tgt.y(), ctx->tgt.z(), nullptr, nullptr, nullptr,
+  b.im[1] = BpImage{img_t, ctx->tgt.x(), ctx->tgt.y(), ctx->tgt.z(), nullptr, nullptr, nullptr,
                     ctx->bp_counts + per_image, __builtin_inff()};
   Rt rt{};
   if (R) {
@@ -2085,6 +2104,10 @@ int icpk_backproject_pair(icpk_ctx* ctx, const uint16_t* depth_source, const uin
   ctx->have_src = ctx->have_tgt = true;
   ctx->have_assoc = ctx->have_seed = ctx->have_qperm = false;
   ctx->have_dec = ctx->have_boxes = ctx->have_grid = ctx->have_normals = false;
+  ctx->frame_slot = sslot;
+  ctx->frame_rows = rows;
+  ctx->frame_cols = cols;
+  std::memcpy(ctx->frame_filter, fset, sizeof(fset));
   if (n_source) *n_source = ctx->src.n;
   if (n_target) *n_target = ctx->tgt.n;
   return ICPK_OK;
@@ -2112,6 +2135,7 @@ int icpk_filter_depth_image(icpk_ctx* ctx, const uint16_t* depth_in, uint16_t* d
   const int npix = rows * cols;
   rc = ensure_depth_buffers(ctx, npix, 0);
   if (rc) return rc;
+  ctx->frame_slot = -1;  // (the image buffers are shared with icpk_backproject_pair's resident frame)
   ICPK_HIP(ctx, hipMemcpyAsync(ctx->depth_dev, depth_in, (size_t)npix * sizeof(uint16_t), hipMemcpyHostToDevice, ctx->stream));
   launch_depth_filter(ctx->depth_dev, ctx->depth_flt, rows, cols, min_d, max_d, ax, ay, morph != 0, ctx->stream);
   ICPK_HIP(ctx, hipGetLastError());

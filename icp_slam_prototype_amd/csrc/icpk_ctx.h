@@ -85,6 +85,11 @@ struct icpk_ctx {
   int32_t* ks_buf = nullptr;      // key-point association lists: assoc_q | assoc_t | assoc_d | rej_q, ks_cap entries each
   int ks_cap = 0;
   int depth_cap = 0;
+  // icpk_backproject_pair keeps the current frame's image on the device (slot frame_slot of depth_dev / depth_flt, two
+  // slots of depth_cap / 2 pixels): it is the next call's `previous` (SLAM.cpp:305) and need not cross PCIe again
+  int frame_slot = -1;               // -1: no resident frame
+  int frame_rows = 0, frame_cols = 0;
+  int frame_filter[6] = {0, 0, 0, 0, 0, 0};  // filter settings the resident filtered copy was made with (on, max, min, morph, ax, ay)
   int* bp_counts = nullptr;
   int bp_counts_cap = 0;
   int* bp_n_host = nullptr;  // pinned

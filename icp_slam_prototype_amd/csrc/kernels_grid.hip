@@ -186,14 +186,14 @@ __global__ void grid_qscatter_batch_kernel(const SetupBatchOf<QscatterArgs> b) {
 // The number of cells lives in GridInfo ON THE DEVICE; these kernels read it there, so the whole
 // grid build is enqueued without a host round trip (the frame-batch mode builds the grids of the
 // next group while the current group's loop keeps the GPU busy: a host wait there costs
-// milliseconds).  Launch geometry covers GRID_MAX_CELLS + 1; workgroups beyond the actual size
-// leave at once.  Scan in two launches: 2048 counts per workgroup (256 lanes x 8) -> block sums;
-// then every block adds up the sums of the blocks before it (<= 2049 values, 8 per lane) and scans
-// its own counts from there -- and leaves them ZERO: the count table is all zero between two sorts
+// milliseconds).  A fixed launch geometry walks whatever the table size turns out to be.  Scan in two
+// launches: 2048 counts per tile (256 lanes x 8) -> tile sums; then every tile adds up the sums of the tiles
+// before it (<= 4097 values, 16 per lane) and scans its own counts from there -- and leaves them ZERO: the
+// count table is all zero between two sorts
 // (hipMemset at allocation), so no sort starts with a zero-fill launch.
 constexpr int GSCAN_ITEMS = 8;
 constexpr int GSCAN_TILE = 256 * GSCAN_ITEMS;
-constexpr int GSCAN_MAX_BLOCKS = (GRID_MAX_CELLS + 1 + GSCAN_TILE - 1) / GSCAN_TILE;  // 2049
+constexpr int GSCAN_MAX_BLOCKS = (GRID_MAX_CELLS + 1 + GSCAN_TILE - 1) / GSCAN_TILE;  // tiles of the largest table: 4097
 
 __device__ __forceinline__ int grid_table_size(const GridInfo* __restrict__ gi, int coarse) {
   return (coarse ? gi->ncells_q : gi->ncells) + 1;
@@ -209,68 +209,76 @@ __device__ __forceinline__ int block_sum_256(int v, int* sh) {  // sum over the 
   return t;
 }
 
-__device__ __forceinline__ void grid_scan_sums_body(const ScanArgs& a, const int block) {
+// Both kernels walk the table's tiles with the stride of the launch: GSCAN_LAUNCH_BLOCKS workgroups serve any table
+// size (a Kinect-size grid has ~430 tiles; launching the 4097 workgroups of the largest table cost ~3 us per kernel in
+// workgroups that left at once).
+constexpr int GSCAN_LAUNCH_BLOCKS = 512;
+
+__device__ __forceinline__ void grid_scan_sums_body(const ScanArgs& a, const int block, const int nblocks) {
   __shared__ int sh[4];
   const int n = grid_table_size(a.g, a.coarse);
-  const int base = block * GSCAN_TILE;
-  if (base >= n) return;
-  int v = 0;
+  for (int tile = block; tile * GSCAN_TILE < n; tile += nblocks) {
+    const int base = tile * GSCAN_TILE;
+    int v = 0;
 #pragma unroll
-  for (int k = 0; k < GSCAN_ITEMS; ++k) {
-    const int i = base + k * 256 + threadIdx.x;
-    v += i < n ? a.count[i] : 0;
+    for (int k = 0; k < GSCAN_ITEMS; ++k) {
+      const int i = base + k * 256 + threadIdx.x;
+      v += i < n ? a.count[i] : 0;
+    }
+    const int t = block_sum_256(v, sh);
+    if (threadIdx.x == 0) a.bsum[tile] = t;
   }
-  const int t = block_sum_256(v, sh);
-  if (threadIdx.x == 0) a.bsum[block] = t;
 }
-__global__ __launch_bounds__(256) void grid_scan_sums_kernel(const ScanArgs a) { grid_scan_sums_body(a, blockIdx.x); }
+__global__ __launch_bounds__(256) void grid_scan_sums_kernel(const ScanArgs a) { grid_scan_sums_body(a, blockIdx.x, gridDim.x); }
 __global__ __launch_bounds__(256) void grid_scan_sums_batch_kernel(const SetupBatchOf<ScanArgs> b) {
-  grid_scan_sums_body(b.p[blockIdx.y], blockIdx.x);
+  grid_scan_sums_body(b.p[blockIdx.y], blockIdx.x, gridDim.x);
 }
 
-__device__ __forceinline__ void grid_scan_apply_body(const ScanArgs& a, const int block) {
+__device__ __forceinline__ void grid_scan_apply_body(const ScanArgs& a, const int block, const int nblocks) {
   __shared__ int wtot[4];
   __shared__ int sh[4];
   int* __restrict__ in = a.count;
   const int n = grid_table_size(a.g, a.coarse);
-  const int base = block * GSCAN_TILE;
-  if (base >= n) return;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  // this block's offset: the sums of the blocks before it
-  int before = 0;
-  for (int b = t; b < block; b += 256) before += a.bsum[b];
-  const int boff = block_sum_256(before, sh);
-  // lane t owns the 8 consecutive counts base + 8 t .. base + 8 t + 7
-  int c[GSCAN_ITEMS], s = 0;
+  for (int tile = block; tile * GSCAN_TILE < n; tile += nblocks) {
+    const int base = tile * GSCAN_TILE;
+    // this tile's offset: the sums of the tiles before it
+    int before = 0;
+    for (int b = t; b < tile; b += 256) before += a.bsum[b];
+    const int boff = block_sum_256(before, sh);
+    // lane t owns the 8 consecutive counts base + 8 t .. base + 8 t + 7
+    int c[GSCAN_ITEMS], s = 0;
 #pragma unroll
-  for (int k = 0; k < GSCAN_ITEMS; ++k) {
-    const int i = base + GSCAN_ITEMS * t + k;
-    c[k] = i < n ? in[i] : 0;
-    s += c[k];
-  }
-  int inc = s;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const int o = __shfl_up(inc, d, 64);
-    if (lane >= d) inc += o;
-  }
-  if (lane == 63) wtot[wave] = inc;
-  __syncthreads();
-  int run = boff + inc - s;
-  for (int w = 0; w < wave; ++w) run += wtot[w];
-#pragma unroll
-  for (int k = 0; k < GSCAN_ITEMS; ++k) {
-    const int i = base + GSCAN_ITEMS * t + k;
-    if (i < n) {
-      a.out[i] = run;
-      in[i] = 0;  // the table is handed back all zero
+    for (int k = 0; k < GSCAN_ITEMS; ++k) {
+      const int i = base + GSCAN_ITEMS * t + k;
+      c[k] = i < n ? in[i] : 0;
+      s += c[k];
     }
-    run += c[k];
+    int inc = s;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int o = __shfl_up(inc, d, 64);
+      if (lane >= d) inc += o;
+    }
+    __syncthreads();  // (wtot of the previous tile has been read)
+    if (lane == 63) wtot[wave] = inc;
+    __syncthreads();
+    int run = boff + inc - s;
+    for (int w = 0; w < wave; ++w) run += wtot[w];
+#pragma unroll
+    for (int k = 0; k < GSCAN_ITEMS; ++k) {
+      const int i = base + GSCAN_ITEMS * t + k;
+      if (i < n) {
+        a.out[i] = run;
+        in[i] = 0;  // the table is handed back all zero
+      }
+      run += c[k];
+    }
   }
 }
-__global__ __launch_bounds__(256) void grid_scan_apply_kernel(const ScanArgs a) { grid_scan_apply_body(a, blockIdx.x); }
+__global__ __launch_bounds__(256) void grid_scan_apply_kernel(const ScanArgs a) { grid_scan_apply_body(a, blockIdx.x, gridDim.x); }
 __global__ __launch_bounds__(256) void grid_scan_apply_batch_kernel(const SetupBatchOf<ScanArgs> b) {
-  grid_scan_apply_body(b.p[blockIdx.y], blockIdx.x);
+  grid_scan_apply_body(b.p[blockIdx.y], blockIdx.x, gridDim.x);
 }
 
 // coarse = 1: the table of the query order (ncells_q entries), else the targets' (ncells).
@@ -289,13 +297,13 @@ __global__ __launch_bounds__(256) void grid_scan_apply_batch_kernel(const SetupB
 void launch_grid_scan(int* count, int* out, int* bsum, const GridInfo* g, int coarse, hipStream_t s) {
   const ScanArgs a{count, out, bsum, g, coarse, 0};
   ICPK_RECORD(SK_SCAN, scan, a)
-  hipLaunchKernelGGL(grid_scan_sums_kernel, dim3(GSCAN_MAX_BLOCKS), dim3(256), 0, s, a);
-  hipLaunchKernelGGL(grid_scan_apply_kernel, dim3(GSCAN_MAX_BLOCKS), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(grid_scan_sums_kernel, dim3(GSCAN_LAUNCH_BLOCKS), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(grid_scan_apply_kernel, dim3(GSCAN_LAUNCH_BLOCKS), dim3(256), 0, s, a);
 }
 void launch_grid_scan_batch(const SetupBatchOf<ScanArgs>& b, int count, hipStream_t s) {
   if (count <= 0) return;
-  hipLaunchKernelGGL(grid_scan_sums_batch_kernel, dim3(GSCAN_MAX_BLOCKS, count), dim3(256), 0, s, b);
-  hipLaunchKernelGGL(grid_scan_apply_batch_kernel, dim3(GSCAN_MAX_BLOCKS, count), dim3(256), 0, s, b);
+  hipLaunchKernelGGL(grid_scan_sums_batch_kernel, dim3(GSCAN_LAUNCH_BLOCKS, count), dim3(256), 0, s, b);
+  hipLaunchKernelGGL(grid_scan_apply_batch_kernel, dim3(GSCAN_LAUNCH_BLOCKS, count), dim3(256), 0, s, b);
 }
 
 // targets into the AoS copy (x, y, z, original index), one 16-byte load per candidate -- and, in the

@@ -257,7 +257,9 @@ class Tracker {
 
   // Same meaning as icp::getTransformation(data, previous, ..., maxIterations, threshold):
   // returns the status, writes the 4x4 into T (row-major).  `data` is the current
-  // frame, `previous` the frame before it.
+  // frame, `previous` the frame before it.  previous == nullptr: the frame that was `data` in the
+  // last call -- what SLAM.cpp hands back (SLAM.cpp:305, previous = filtered.clone()); it has stayed
+  // on the device, so only the new frame is uploaded (same results as passing it again).
   int getTransformation(const uint16_t* data, const uint16_t* previous, int rows, int cols, int maxIterations,
                         float threshold, float T[16]) {
     icpk_ctx* c = eng_.ctx();

@@ -308,7 +308,12 @@ int icpk_backproject_filtered(icpk_ctx *ctx, const uint16_t *depth, int32_t rows
  * runs icpk_filter_depth_image's filter (max_d ... anchor_y) on both frames first.  Equivalent, bit for bit,
  * to icpk_backproject[_filtered] x 2 + icpk_transform_target + icpk_transform_source + icpk_commit_source
  * (the posed source is the starting point of the alignment), with 3-5 kernel launches instead of 25
- * and one host wait instead of two.  *n_source / *n_target: the cloud sizes. */
+ * and one host wait instead of two.  *n_source / *n_target: the cloud sizes.
+ * depth_target == NULL: the previous frame is the one this context received as depth_source in its last
+ * icpk_backproject_pair call (SLAM.cpp:305, previous = filtered.clone(): the caller hands the same frame back) --
+ * its image, and its filtered copy if the filter settings are unchanged, are still on the device, so only ONE
+ * image crosses PCIe.  Same results as passing the frame again.  ICPK_E_NOT_SET if no frame of this size is
+ * resident (first call, other rows / cols, or the image buffers were used by another call in between). */
 int icpk_backproject_pair(icpk_ctx *ctx, const uint16_t *depth_source, const uint16_t *depth_target,
                           int32_t rows, int32_t cols, float fx, float cx, const float offset[3],
                           const float R[9], const float t[3], int32_t filter, int32_t max_d, int32_t min_d,

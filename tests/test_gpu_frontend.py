@@ -210,6 +210,50 @@ def test_backproject_pair_equals_the_separate_calls(rows, cols, filt):
                 assert b.backproject_pair(dt, ds, R=pose[0], t=pose[1], fx=fx, cx=cx, offset=off, filter=filt) == (nt, ns)
 
 
+@pytest.mark.parametrize("filt", [False, True])
+def test_backproject_pair_with_the_resident_previous_frame(filt):
+    """SLAM.cpp:305 hands the last frame back as `previous`: with depth_target = None the frame this context received
+    as depth_source last time is taken from the device (one upload per call instead of two) -- clouds, alignment,
+    trace and aligned source equal, bit for bit, those of the call that passes both images, over a sequence of frames
+    with a moving pose; a changed filter setting re-filters the resident frame; without a resident frame of the
+    right size the call is refused."""
+    rows, cols = 120, 160
+    fx, cx = float(synth.FX) * cols / 640, float(synth.CX) * cols / 640
+    rng = np.random.default_rng(5)
+    frames = []
+    for k in range(5):
+        d = synth.render_room_depth(rows, cols, synth.rot_xyz_deg(0, 0.6 * k, 0.2 * k), np.array([0.01 * k, 0, 0.005 * k]),
+                                    fx, cx, noise_sigma=0.002, rng=rng)
+        d[rng.random(d.shape) > 0.6] = 0
+        d[::7, ::5] = 30000 if k % 2 else 300  # outside [minDistance, maxDistance]: matters only when filtered
+        frames.append(d.astype(np.uint16))
+    with binding.Context(0) as a, binding.Context(0) as b:
+        with pytest.raises(binding.IcpkError) as e:
+            b.backproject_pair(frames[0], None, fx=fx, cx=cx)
+        assert e.value.code == binding.E_NOT_SET
+        for k in range(1, len(frames)):
+            R = binding.make_rotation_matrix(0.3 * k, -0.2 * k, 0.1)
+            t = np.array([5 + 0.01 * k, 5, 5], np.float32)
+            kw = dict(R=R, t=t, fx=fx, cx=cx, filter=filt, max_d=25000 - (500 if k == 3 else 0))
+            want = a.backproject_pair(frames[k], frames[k - 1], **kw)
+            got = b.backproject_pair(frames[k], frames[k - 1] if k == 1 else None, **kw)
+            assert got == want
+            assert a.get_source().tobytes() == b.get_source().tobytes() and a.get_target().tobytes() == b.get_target().tobytes()
+            ra = a.align(max_iterations=16, threshold=1e-4)
+            rb = b.align(max_iterations=16, threshold=1e-4)
+            assert np.array_equal(ra[0], rb[0]) and ra[1].iterations == rb[1].iterations and ra[1].final_pairs == rb[1].final_pairs
+            assert a.get_source().tobytes() == b.get_source().tobytes()
+        # other sizes / another user of the image buffers in between: refused, then fine again with both images
+        with pytest.raises(binding.IcpkError):
+            b.backproject_pair(frames[0][:60], None, fx=fx, cx=cx)
+        b.backproject(frames[0], which=1, fx=fx, cx=cx)
+        with pytest.raises(binding.IcpkError):
+            b.backproject_pair(frames[1], None, fx=fx, cx=cx)
+        assert b.backproject_pair(frames[2], frames[1], fx=fx, cx=cx) == a.backproject_pair(frames[2], frames[1], fx=fx, cx=cx)
+        assert b.backproject_pair(frames[3], None, fx=fx, cx=cx) == a.backproject_pair(frames[3], frames[2], fx=fx, cx=cx)
+        assert a.get_target().tobytes() == b.get_target().tobytes()
+
+
 def test_backproject_pair_empty_frames_and_bad_arguments():
     z = np.zeros((24, 40), np.uint16)
     d = z.copy()
