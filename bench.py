@@ -623,7 +623,7 @@ def bench_frame_batch(args, torch, dist, rank, world, dev, cdev, gpu_index, rehe
     comm = None
     comm_err = None
     # (rehearsal on one GPU: the C-ABI communicator only with the shared-memory stand-in of the tests)
-    if args.comm in ("auto", "icpk") and (not rehearsal or os.environ.get("ICPK_RCCL_LIB")):
+    if args.comm in ("auto", "icpk") and (not rehearsal or (os.environ.get("ICPK_TEST_HOOKS") == "1" and os.environ.get("ICPK_RCCL_LIB"))):
         def exchange(uid):  # rank 0's 128-byte id to everybody, over the launcher's process group
             box = [uid]
             dist.broadcast_object_list(box, src=0)
@@ -648,12 +648,18 @@ def bench_frame_batch(args, torch, dist, rank, world, dev, cdev, gpu_index, rehe
         dist.barrier()
         torch.cuda.synchronize()
 
+    t_align, t_gather = [], []  # this rank's host wall time per step: its block of pairs / the all-gather (incl. waiting for the slowest rank)
+
     def step():
+        ta = time.perf_counter()
         T, st, rc = ctx.align_batch_device(pargs, params)
+        tb = time.perf_counter()
         if isinstance(comm, batch.RcclComm):
             Tg, Sg = comm.gather_results(T, st, n_pairs)
         else:
             Tg, Sg = comm.gather_results(T, batch.stats_rows(st), n_pairs)
+        t_align.append(tb - ta)
+        t_gather.append(time.perf_counter() - tb)
         return rc, Tg, Sg
 
     step()  # set-up, before the W warm-up steps: the first call allocates the slots
@@ -662,6 +668,7 @@ def bench_frame_batch(args, torch, dist, rank, world, dev, cdev, gpu_index, rehe
     gc.collect()
     gc.disable()  # (the interpreter's generation-2 collections take tens of ms: several steps of this workload)
     sync_all()
+    del t_align[:], t_gather[:]
     t0 = time.perf_counter()
     for _ in range(args.steps):
         rc, Tg, Sg = step()
@@ -671,6 +678,11 @@ def bench_frame_batch(args, torch, dist, rank, world, dev, cdev, gpu_index, rehe
     tt = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     elapsed = float(tt.item())
+    # per-rank step times (mean over the timed steps), so that the spread between ranks is readable from the one line
+    mine = torch.tensor([statistics.mean(t_align) * 1e3, statistics.mean(t_gather) * 1e3], dtype=torch.float64, device=cdev)
+    per_rank = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(per_rank, mine)
+    per_rank = [[round(float(v), 4) for v in t.cpu()] for t in per_rank]
     # every rank holds the same gathered result, every pair ran its 20 iterations
     chk = torch.tensor(np.concatenate([Tg.reshape(-1), Sg.reshape(-1)]).astype(np.float64), device=cdev)
     lo, hi = chk.clone(), chk.clone()
@@ -704,8 +716,30 @@ def bench_frame_batch(args, torch, dist, rank, world, dev, cdev, gpu_index, rehe
             nt0 = ctx.target_size
         except Exception as e:  # noqa: BLE001
             bcast_err = repr(e)
+    # the SAME batch on ONE GPU (rank 0's), outside the timed region: the reference the N-GPU value scales against
+    single = None
+    try:
+        if rank == 0:
+            keep1, pargs1 = batch_pairs_on_device(torch, dev, range(n_pairs))
+            for _ in range(2):
+                ctx.align_batch_device(pargs1, params)
+            each = []
+            for _ in range(5):
+                torch.cuda.synchronize()
+                tb = time.perf_counter()
+                _, st1, _ = ctx.align_batch_device(pargs1, params)
+                torch.cuda.synchronize()
+                each.append(time.perf_counter() - tb)
+            d1 = statistics.median(each)
+            single = {"ms_per_batch": d1 * 1e3, "value": sum(x.iterations for x in st1) / d1, "unit": "iter/s",
+                      "timing": "median of 5 calls of icpk_align_batch_device on rank 0's GPU, the other ranks idle"}
+            del keep1
+    except Exception as e:  # noqa: BLE001 -- auxiliary: never let it cost the line
+        single = {"error": repr(e)}
+    dist.barrier()
     if rank == 0:
         total_iters = float(Sg[:, 0].sum()) * args.steps
+        al = [r[0] for r in per_rank]
         out = {
             "metric": METRIC, "value": total_iters / elapsed, "unit": "iter/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
@@ -717,6 +751,10 @@ def bench_frame_batch(args, torch, dist, rank, world, dev, cdev, gpu_index, rehe
                        "parallelism": f"frame-batch x{world}: block partition, no per-iteration collective, one all-gather "
                                       f"of the results per step"},
             "roofline": roof,
+            "per_rank_ms_per_step": {"align_batch_device": al, "gather_results_incl_wait": [r[1] for r in per_rank],
+                                     "align_min": min(al), "align_max": max(al)},
+            "single_gpu_reference": single,
+            "speedup_vs_single_gpu": (total_iters / elapsed / single["value"]) if single and "value" in single else None,
             "collectives": comm.kind, "collectives_fallback_reason": comm_err,
             "results_consistent_on_all_ranks": consistent,
             "keyframe_broadcast_ms": bcast_ms, "keyframe_broadcast_error": bcast_err,

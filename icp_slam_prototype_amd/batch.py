@@ -29,8 +29,8 @@ def partition(n_items, world, rank):
 
 
 def stats_rows(stats):
-    """list of binding.Stats -> (b, 4) float32 rows [iterations, status, pairs, mse]"""
-    return np.array([[s.iterations, s.status, s.final_pairs, s.final_mse] for s in stats], np.float32).reshape(-1, 4)
+    """list of binding.Stats -> (b, 4) float64 rows [iterations, status, pairs, mse]"""
+    return np.array([[s.iterations, s.status, s.final_pairs, s.final_mse] for s in stats], np.float64).reshape(-1, 4)
 
 
 class TorchComm:
@@ -57,8 +57,9 @@ class TorchComm:
         return t
 
     def gather_results(self, T_local, S_local, n_total):
-        """T_local (b, 4, 4), S_local (b, 4) of this rank's block -> (n_total, 4, 4), (n_total, 4)
-        in global pair order, identical on every rank."""
+        """T_local (b, 4, 4), S_local (b, 4) of this rank's block -> (n_total, 4, 4), (n_total, 4) float64
+        in global pair order, identical on every rank.  (iterations, status and pairs cross the collective as int32
+        bit patterns in their float slots, like icpk_comm_gather_results: exact for any cloud size.)"""
         import torch
 
         bmax = max(partition(n_total, self.world, r)[1] for r in range(self.world))
@@ -66,16 +67,21 @@ class TorchComm:
         b = T_local.shape[0]
         if b:
             buf[:b, :16] = torch.as_tensor(np.ascontiguousarray(T_local, np.float32).reshape(b, 16)).to(self.device)
-            buf[:b, 16:] = torch.as_tensor(np.ascontiguousarray(S_local, np.float32)).to(self.device)
+            S_local = np.asarray(S_local, np.float64).reshape(b, 4)
+            row = np.empty((b, 4), np.float32)
+            row[:, :3] = np.rint(S_local[:, :3]).astype(np.int32).view(np.float32)
+            row[:, 3] = S_local[:, 3]
+            buf[:b, 16:] = torch.as_tensor(row).to(self.device)
         out = [torch.empty_like(buf) for _ in range(self.world)]
         self.dist.all_gather(out, buf)
         T = np.zeros((n_total, 4, 4), np.float32)
-        S = np.zeros((n_total, 4), np.float32)
+        S = np.zeros((n_total, 4), np.float64)
         for r in range(self.world):
             s, c = partition(n_total, self.world, r)
-            a = out[r][:c].cpu().numpy()
+            a = np.ascontiguousarray(out[r][:c].cpu().numpy())
             T[s:s + c] = a[:, :16].reshape(c, 4, 4)
-            S[s:s + c] = a[:, 16:]
+            S[s:s + c, :3] = np.ascontiguousarray(a[:, 16:19]).view(np.int32)
+            S[s:s + c, 3] = a[:, 19]
         return T, S
 
     def allreduce_sums(self, sums, count):
@@ -135,7 +141,7 @@ def align_pair_batch(n_pairs, make_pair, align_batch_fn, comm):
         T_local, S_local = align_batch_fn(pairs)
     else:
         T_local, S_local = np.zeros((0, 4, 4), np.float32), np.zeros((0, 4), np.float32)
-    return comm.gather_results(np.asarray(T_local, np.float32), np.asarray(S_local, np.float32), n_pairs)
+    return comm.gather_results(np.asarray(T_local, np.float32), np.asarray(S_local, np.float64), n_pairs)
 
 
 # torch.distributed spellings kept for callers that hold a process group
@@ -156,7 +162,7 @@ def align_frame_batch(make_source, n_frames, target_on_rank0, align_fn, device, 
     tgt = comm.broadcast_cloud(target_on_rank0, 0)
     start, count = partition(n_frames, comm.world, comm.rank)
     T_local = np.zeros((count, 4, 4), np.float32)
-    S_local = np.zeros((count, 4), np.float32)
+    S_local = np.zeros((count, 4), np.float64)
     for k in range(count):
         T, it, status, pairs, mse = align_fn(make_source(start + k), tgt)
         T_local[k] = T

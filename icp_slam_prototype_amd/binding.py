@@ -571,7 +571,8 @@ class Context:
 
     def comm_gather_results(self, T_local, stats_local, n_total):
         """T_local (b, 4, 4) float32 and the list of Stats of this rank's block -> (T (n_total, 4, 4),
-        S (n_total, 4) = iterations, status, pairs, mse), identical on every rank."""
+        S (n_total, 4) float64 = iterations, status, pairs, mse), identical on every rank.  (The integers cross the
+        collective as int32 bit patterns: exact for any cloud size.)"""
         T_local = np.ascontiguousarray(T_local, np.float32).reshape(-1, 16)
         b = T_local.shape[0]
         st = (Stats * max(b, 1))()
@@ -584,7 +585,10 @@ class Context:
         T = np.zeros((max(n_total, 1), 16), np.float32)
         S = np.zeros((max(n_total, 1), 4), np.float32)
         self._chk(self._lib.icpk_comm_gather_results(self._h, _fp(T_local) if b else None, st, b, n_total, _fp(T), _fp(S)))
-        return T[:n_total].reshape(n_total, 4, 4), S[:n_total]
+        out = np.empty((n_total, 4), np.float64)
+        out[:, :3] = S[:n_total, :3].view(np.int32)
+        out[:, 3] = S[:n_total, 3]
+        return T[:n_total].reshape(n_total, 4, 4), out
 
     def comm_allreduce_sums(self, sums, count):
         sums = np.ascontiguousarray(sums, np.float64).copy()

@@ -1808,6 +1808,29 @@ int align_batch_impl(icpk_ctx* ctx, int32_t n_pairs, const icpk_pair* pairs, con
   GroupRun prev;
   bool have_prev = false;
   std::vector<icpk_ctx*> unfinished;  // slots whose set-up stopped half-way (see the end of this function)
+  // Every way out of the loop below, error or not, goes through the same tail: the previous group's results are
+  // delivered, and nothing of this call is still in flight when it returns -- set-up kernels may be reading the
+  // caller's device-resident clouds, uploads may be reading the caller's host buffers or a slot's staging area.
+  auto drain = [&]() {
+    (void)hipStreamSynchronize(ctx->stream);
+    for (hipStream_t st : {ctx->setup_stream[0], ctx->setup_stream[1]})
+      if (st) (void)hipStreamSynchronize(st);
+    for (icpk_ctx* sl : ctx->slots) (void)hipStreamSynchronize(sl->stream);
+  };
+  auto bail = [&](int code) {
+    if (have_prev) finish_group(prev);
+    have_prev = false;
+    drain();
+    return code;
+  };
+#define ICPK_HIP_BAIL(call)                                                      \
+  do {                                                                           \
+    hipError_t e__ = (call);                                                     \
+    if (e__ != hipSuccess) {                                                     \
+      ctx->err = std::string(#call) + ": " + hipGetErrorString(e__);             \
+      return bail(ICPK_E_HIP);                                                   \
+    }                                                                            \
+  } while (0)
   for (int gi = 0; gi < ngroups; ++gi) {
     const auto t0 = now();
         GroupRun g;
@@ -1848,8 +1871,8 @@ int align_batch_impl(icpk_ctx* ctx, int32_t n_pairs, const icpk_pair* pairs, con
     const int nthreads = batched || kind == hipMemcpyHostToDevice ? 1 : (g.count < ctx->batch_threads ? g.count : ctx->batch_threads);
     if (batched) {
       if (!ctx->setup_stream[g.set]) {
-        ICPK_HIP(ctx, hipStreamCreateWithFlags(&ctx->setup_stream[g.set], hipStreamNonBlocking));
-        ICPK_HIP(ctx, hipEventCreateWithFlags(&ctx->setup_ev[g.set], hipEventDisableTiming));
+        ICPK_HIP_BAIL(hipStreamCreateWithFlags(&ctx->setup_stream[g.set], hipStreamNonBlocking));
+        ICPK_HIP_BAIL(hipEventCreateWithFlags(&ctx->setup_ev[g.set], hipEventDisableTiming));
       }
       const hipStream_t ss = ctx->setup_stream[g.set];
       std::vector<SetupRecorder> recs(g.count);
@@ -1865,6 +1888,12 @@ int align_batch_impl(icpk_ctx* ctx, int32_t n_pairs, const icpk_pair* pairs, con
         setup_one(k);
         setup_recorder() = nullptr;
         sl->stream = own;
+        if (g.rc[k] == ICPK_OK && recs[k].overflow) {
+          // more set-up steps than the recorder holds: the launches beyond its capacity were never issued --
+          // the pair must not run on half a set-up
+          device_loop_disarm(sl);
+          g.rc[k] = fail(sl, ICPK_E_HIP, "frame-batch set-up recorder overflow (SETUP_MAX_CALLS)");
+        }
         recorded[k] = g.rc[k] == ICPK_OK;
       }
       std::vector<SetupRecorder> ok;
@@ -1873,8 +1902,8 @@ int align_batch_impl(icpk_ctx* ctx, int32_t n_pairs, const icpk_pair* pairs, con
       if (!ok.empty()) {
         if (ctx->batch_setup == 3 /* test hook: the pair-by-pair replay */ || !flush_setup_batches(ok.data(), (int)ok.size(), ss))
           for (const SetupRecorder& r : ok) replay_setup(r, ss);
-        ICPK_HIP(ctx, hipGetLastError());
-        ICPK_HIP(ctx, hipEventRecord(ctx->setup_ev[g.set], ss));
+        ICPK_HIP_BAIL(hipGetLastError());
+        ICPK_HIP_BAIL(hipEventRecord(ctx->setup_ev[g.set], ss));
       }
     } else if (nthreads <= 1) {
       for (int k = 0; k < g.count; ++k) setup_one(k);
@@ -1902,10 +1931,9 @@ int align_batch_impl(icpk_ctx* ctx, int32_t n_pairs, const icpk_pair* pairs, con
     }
     const auto t2 = now();
     rc = enqueue_group_loop(ctx, p, act, first, g.set, own_event);
-    if (rc) {  // enqueue failed: nothing of this group can be trusted
+    if (rc) {  // enqueue failed: nothing of this group can be trusted (the previous group's results still are)
       for (icpk_ctx* sl : act) device_loop_disarm(sl);
-      (void)hipStreamSynchronize(ctx->stream);
-      return rc;
+      return bail(rc);
     }
     const auto t3 = now();
     if (have_prev) finish_group(prev);
@@ -1927,6 +1955,7 @@ int align_batch_impl(icpk_ctx* ctx, int32_t n_pairs, const icpk_pair* pairs, con
     for (hipStream_t st : {ctx->setup_stream[0], ctx->setup_stream[1]})
       if (st) ICPK_HIP(ctx, hipStreamSynchronize(st));
   if (trace) std::fprintf(stderr, "icpk batch tail: wait+finish last group %.0f us, stream syncs %.0f us\n", us(te0, te1), us(te1, now()));
+#undef ICPK_HIP_BAIL
   return worst;
 }
 

@@ -46,9 +46,12 @@ RcclApi* rccl() {
   static RcclApi api;
   static std::once_flag once;
   std::call_once(once, [] {
-    // ICPK_RCCL_LIB: test hook -- tests/cpp/fake_rccl.cpp stands in for RCCL so that two ranks sharing
-    // the one GPU of the test box can exercise the world > 1 paths below (real RCCL refuses that)
-    const char* over = std::getenv("ICPK_RCCL_LIB");
+    // Test hook, honoured ONLY when ICPK_TEST_HOOKS=1 is set as well: ICPK_RCCL_LIB names a library that stands in
+    // for RCCL (tests/cpp/fake_rccl.cpp), so that two ranks sharing the one GPU of the test box can exercise the
+    // world > 1 paths below (real RCCL refuses that).  Without the switch the variable is ignored: a production
+    // process never opens a library because an environment variable says so.
+    const char* sw = std::getenv("ICPK_TEST_HOOKS");
+    const char* over = (sw && sw[0] == '1' && sw[1] == 0) ? std::getenv("ICPK_RCCL_LIB") : nullptr;
     if (over && *over) {
       api.handle = dlopen(over, RTLD_NOW | RTLD_LOCAL);
     } else {
@@ -210,10 +213,18 @@ int icpk_comm_broadcast_target(icpk_ctx* ctx, int root) {
   ICPK_HIP(ctx, hipStreamSynchronize(ctx->stream));
   const int n = *hn;
   if (n < 0) return icpk_host_fail(ctx, ICPK_E_RCCL, "broadcast of the target size failed");
-  if (c->rank != root) {
-    rc = icpk_host_ensure_cloud(ctx, ctx->tgt, n);
-    if (rc) return rc;
-  }
+  // Every rank makes room first and the ranks AGREE on the outcome (one 4-byte all-reduce) before the plane
+  // broadcasts: a rank that could not allocate must not leave the others waiting inside ncclBroadcast.
+  int alloc_rc = ICPK_OK;
+  if (c->rank != root) alloc_rc = icpk_host_ensure_cloud(ctx, ctx->tgt, n);
+  double* hf = static_cast<double*>(c->host);  // (float64 sum: the one all-reduce flavour this layer uses anywhere)
+  *hf = alloc_rc == ICPK_OK ? 0.0 : 1.0;
+  ICPK_HIP(ctx, hipMemcpyAsync(c->dev, hf, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  ICPK_RCCL(ctx, api->AllReduce(c->dev, c->dev, 1, ncclFloat64, ncclSum, c->comm, ctx->stream));
+  ICPK_HIP(ctx, hipMemcpyAsync(hf, c->dev, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  ICPK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (alloc_rc) return alloc_rc;
+  if (*hf != 0.0) return icpk_host_fail(ctx, ICPK_E_HIP, "another rank could not allocate the broadcast target");
   if (n > 0) {  // plane capacities may differ from rank to rank: one message per plane, grouped
     ICPK_RCCL(ctx, api->GroupStart());
     ICPK_RCCL(ctx, api->Broadcast(ctx->tgt.x(), ctx->tgt.x(), (size_t)n, ncclFloat32, root, c->comm, ctx->stream));
@@ -255,10 +266,9 @@ int icpk_comm_gather_results(icpk_ctx* ctx, const float* T_local, const icpk_sta
   std::memset(hs, 0, send * sizeof(float));
   for (int k = 0; k < n_local; ++k) {
     std::memcpy(hs + row * k, T_local + 16 * (size_t)k, 16 * sizeof(float));
-    if (stats_local) {
-      hs[row * k + 16] = (float)stats_local[k].iterations;
-      hs[row * k + 17] = (float)stats_local[k].status;
-      hs[row * k + 18] = (float)stats_local[k].final_pairs;
+    if (stats_local) {  // the three integers travel as int32 bit patterns in their float slots: exact whatever the cloud size
+      const int32_t iv[3] = {stats_local[k].iterations, stats_local[k].status, stats_local[k].final_pairs};
+      std::memcpy(hs + row * k + 16, iv, sizeof(iv));
       hs[row * k + 19] = stats_local[k].final_mse;
     }
   }

@@ -368,8 +368,11 @@ struct SetupCall {
     QscatterArgs qscatter;
   };
 };
+// a pair's set-up is 13 steps today (ingest x 2, loop init, bounds, info, 2 x (slots, scan), target scatter, query
+// scatter + the upload path's extras); a recorder that overflows marks itself and the pair FAILS (align_batch_impl)
+constexpr int SETUP_MAX_CALLS = 24;
 struct SetupRecorder {
-  SetupCall calls[24];
+  SetupCall calls[SETUP_MAX_CALLS];
   int n = 0;
   bool overflow = false;
 };

@@ -193,7 +193,7 @@ __global__ void grid_qscatter_batch_kernel(const SetupBatchOf<QscatterArgs> b) {
 // (hipMemset at allocation), so no sort starts with a zero-fill launch.
 constexpr int GSCAN_ITEMS = 8;
 constexpr int GSCAN_TILE = 256 * GSCAN_ITEMS;
-constexpr int GSCAN_MAX_BLOCKS = (GRID_MAX_CELLS + 1 + GSCAN_TILE - 1) / GSCAN_TILE;  // tiles of the largest table: 4097
+// (the largest table, 2^23 + 1 entries, has 4097 tiles)
 
 __device__ __forceinline__ int grid_table_size(const GridInfo* __restrict__ gi, int coarse) {
   return (coarse ? gi->ncells_q : gi->ncells) + 1;
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(256) void grid_scan_apply_batch_kernel(const SetupB
 // out[i] = sum of count[0 .. i) for i in [0, size]; count[] is zero afterwards; bsum: GRID_SCAN_BLOCKS ints
 #define ICPK_RECORD(KIND, FIELD, VALUE)           \
   if (SetupRecorder* r__ = setup_recorder()) {    \
-    if (r__->n < 24) {                            \
+    if (r__->n < SETUP_MAX_CALLS) {                            \
       r__->calls[r__->n].kind = KIND;             \
       r__->calls[r__->n++].FIELD = VALUE;         \
     } else {                                      \

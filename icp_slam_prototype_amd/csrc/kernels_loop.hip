@@ -257,7 +257,7 @@ __global__ __launch_bounds__(64) void loop_init_batch_kernel(const SetupBatchOf<
 
 void launch_loop_init(const LoopInitArgs& a, hipStream_t s) {
   if (SetupRecorder* r = setup_recorder()) {
-    if (r->n < 24) {
+    if (r->n < SETUP_MAX_CALLS) {
       r->calls[r->n].kind = SK_LOOP_INIT;
       r->calls[r->n++].loop_init = a;
     } else {

@@ -92,7 +92,7 @@ void launch_ingest_cloud(const float* x, const float* y, const float* z, int n, 
   if (n_pad <= 0) return;
   IngestArgs a{x, y, z, n, n_pad, pad, cap1, d1, d2, cap2, 0};
   if (SetupRecorder* r = setup_recorder()) {
-    if (r->n < 24) {
+    if (r->n < SETUP_MAX_CALLS) {
       r->calls[r->n].kind = SK_INGEST;
       r->calls[r->n++].ingest = a;
     } else {

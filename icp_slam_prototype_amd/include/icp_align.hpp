@@ -161,9 +161,11 @@ class Comm {
     for (int32_t k = 0; k < n_total; ++k) {
       AlignResult& r = (*all)[(size_t)k];
       std::memcpy(r.T, Ta.data() + 16 * (size_t)k, 16 * sizeof(float));
-      r.stats.iterations = (int32_t)Sa[4 * (size_t)k];
-      r.status = r.stats.status = (int32_t)Sa[4 * (size_t)k + 1];
-      r.stats.final_pairs = (int32_t)Sa[4 * (size_t)k + 2];
+      int32_t iv[3];  // (int32 bit patterns in the first three slots of a row)
+      std::memcpy(iv, Sa.data() + 4 * (size_t)k, sizeof(iv));
+      r.stats.iterations = iv[0];
+      r.status = r.stats.status = iv[1];
+      r.stats.final_pairs = iv[2];
       r.stats.final_mse = Sa[4 * (size_t)k + 3];
     }
     return ICPK_OK;

@@ -265,8 +265,9 @@ void icpk_comm_partition(int32_t n_items, int world, int rank, int32_t *start, i
 int icpk_comm_broadcast_target(icpk_ctx *ctx, int root);
 /* results of a block-partitioned batch of n_total pairs: this rank contributes the n_local
  * rows of its block (T_local n_local x 16, stats_local n_local or NULL) and receives all rows
- * in global pair order: T_all n_total x 16, stats_all n_total x 4 floats (iterations, status,
- * final_pairs, final_mse; integers travel as floats: exact below 2^24) or NULL.  One ncclAllGather. */
+ * in global pair order: T_all n_total x 16, stats_all n_total x 4 four-byte slots (iterations, status,
+ * final_pairs as int32 BIT PATTERNS -- memcpy them out, exact whatever the cloud size -- and final_mse as a
+ * float) or NULL.  One ncclAllGather. */
 int icpk_comm_gather_results(icpk_ctx *ctx, const float *T_local, const icpk_stats *stats_local,
                              int32_t n_local, int32_t n_total, float *T_all, float *stats_all);
 /* query-sharded single pair (SURVEY.md 8e alternative): sums[0..n) and *count summed over the

@@ -47,7 +47,7 @@ def test_two_rank_frame_batch_line_through_the_c_abi_communicator():
     shared-memory stand-in for the collectives (tests/cpp/fake_rccl.cpp), two ranks on one GPU"""
     from icp_slam_prototype_amd import build
 
-    d = _run({"ICPK_RCCL_LIB": build.build_fake_rccl()})
+    d = _run({"ICPK_TEST_HOOKS": "1", "ICPK_RCCL_LIB": build.build_fake_rccl()})
     assert d["collectives"].startswith("icpk_comm") and d["collectives_fallback_reason"] is None
     assert d["keyframe_broadcast_ms"] is not None and d["keyframe_broadcast_error"] is None
     assert d["keyframe_broadcast_bytes"] > 0

@@ -29,6 +29,7 @@ def _pairs():
 
 def _worker(rank, world, fake, q_id, q_out):
     sys.path.insert(0, ROOT)
+    os.environ["ICPK_TEST_HOOKS"] = "1"  # the switch without which icpk_comm_* ignores ICPK_RCCL_LIB
     os.environ["ICPK_RCCL_LIB"] = fake
     from icp_slam_prototype_amd import batch, binding, synth
 
@@ -56,10 +57,10 @@ def _worker(rank, world, fake, q_id, q_out):
     n_total = 5
     start, count = batch.partition(n_total, world, rank)
     T_local = np.zeros((count, 4, 4), np.float32)
-    S_local = np.zeros((count, 4), np.float32)
+    S_local = np.zeros((count, 4), np.float64)
     for k in range(count):
         T_local[k] = (start + k) * 100 + np.arange(16, dtype=np.float32).reshape(4, 4)
-        S_local[k] = (start + k, 0, 1000 + start + k, 0.5 * (start + k))
+        S_local[k] = (start + k, 0, 100_000_001 + start + k, 0.5 * (start + k))  # (a pair count a float32 cannot hold)
     res["gather"] = comm.gather_results(T_local, S_local, n_total)
     # (3) all-reduce of sums + count
     res["allreduce"] = comm.allreduce_sums(np.arange(19, dtype=np.float64) * (rank + 1), 10 ** 10 * (rank + 1))
@@ -109,7 +110,7 @@ def test_two_ranks_on_one_gpu_through_the_c_abi(oracle):
         assert T.shape == (5, 4, 4) and S.shape == (5, 4)
         for k in range(5):
             assert np.array_equal(T[k], k * 100 + np.arange(16, dtype=np.float32).reshape(4, 4))
-            assert list(S[k]) == [k, 0, 1000 + k, 0.5 * k]
+            assert list(S[k]) == [k, 0, 100_000_001 + k, 0.5 * k]
     # (3)
     for r in (0, 1):
         sums, cnt = got[r]["allreduce"]
