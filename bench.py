@@ -63,6 +63,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--blocks", type=int, default=5, help="N = 1: timed regions of --steps steps each; the median one is reported")
     ap.add_argument("--iters", type=int, default=20, help="fixed ICP iterations per alignment (config 2: 20)")
     ap.add_argument("--workload", default="kinect640x480_30pct",
                     choices=["kinect640x480_30pct", "kinect640x480_dense", "kinect_v2_512x424", "dense1m", "frustum10k"])
@@ -244,11 +245,22 @@ def roofline_blocks(workload, nn_mode, nq, nt, avg_nn_s, timing, kernel):
         traffic = float(e["hbm_bytes_per_launch"])
         phys.update({
             "achieved": traffic / avg_nn_s / 1e9, "frac": traffic / avg_nn_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
-            "traffic_source": "profiles/hbm_traffic.json <- tools/collect_counters.py: (2 x FETCH_SIZE + WRITE_SIZE) KB "
-                              "per NN launch from separate rocprofv3 --pmc passes (gfx950 FETCH_SIZE correction of "
-                              "MI355X_MICROARCH.md); raw CSVs under profiles/",
+            "traffic_source": "profiles/hbm_traffic.json <- tools/collect_counters.py: memory-side read requests by size "
+                              "(128 x RDREQ_128B + 64 x RDREQ_64B + 32 x RDREQ_32B) + WRITE_SIZE per NN launch, separate "
+                              "rocprofv3 --pmc passes on the builder's box (constants here, not re-measured by this run); the "
+                              "counters are calibrated on known byte counts in this kernel's access shapes: "
+                              "profiles/r03_traffic_calibration.txt",
+            "traffic_read_bytes": e.get("read_bytes_per_launch"), "traffic_write_bytes": e.get("write_bytes_per_launch"),
             "compulsory_bytes": float(nq + nt) * 12 + nq * 8,
         })
+        # the same traffic over the kernel's rocprofv3 --kernel-trace duration (no event / dispatch latency in it): with
+        # the event-bracket figure above, `frac` is a range, not a point
+        if e.get("rocprof_avg_launch_ns"):
+            t_k = float(e["rocprof_avg_launch_ns"]) * 1e-9
+            phys["frac_range"] = {"hip_event_bracket": phys["frac"], "rocprof_kernel_duration": traffic / t_k / 1e9 / HBM_PEAK_GBS,
+                                  "rocprof_avg_launch_ms": t_k * 1e3,
+                                  "note": "event bracket measured live by this run (includes ~3-4 us of event / dispatch latency and "
+                                          "the first, unseeded sweep in its share); rocprof duration from profiles/ (builder's box)"}
         if e.get("valu_insts_per_launch"):
             v = float(e["valu_insts_per_launch"])
             phys["valu_insts_per_launch"] = v
@@ -278,7 +290,8 @@ def batch_roofline(stats, group, pairs_per_launch_hint=None):
     icpk_align_batch bracketed with HIP events (params.profile = 1: one batched launch per group, booked on
     the group's first pair, covering all its pairs) and the per-pair counter figures of
     profiles/hbm_traffic.json["frame_batch8:grid"] (a group of 8 config-2 pairs under rocprofv3 --pmc)."""
-    e = pmc_entry("frame_batch8", "grid")
+    e16, e8 = pmc_entry("frame_batch16", "grid"), pmc_entry("frame_batch8", "grid")
+    e, epairs = (e16, 16.0) if (e16 and group >= 16) else (e8, 8.0)  # counters of the launch shape this run times
     t = 0.0
     pair_launches = 0  # pairs covered by the timed launches
     launches = 0
@@ -299,13 +312,17 @@ def batch_roofline(stats, group, pairs_per_launch_hint=None):
                      f"sweeps rotating ({launches} launches over {len(stats)} extra calls after the timed ones; the next group's "
                      "set-up runs beside it on another stream, and the event pair costs ~4 us)"}
     if e:
-        per_pair = float(e["hbm_bytes_per_launch"]) / 8.0
-        v_pair = float(e.get("valu_insts_per_launch") or 0.0) / 8.0
+        per_pair = float(e["hbm_bytes_per_launch"]) / epairs
+        v_pair = float(e.get("valu_insts_per_launch") or 0.0) / epairs
         traffic = per_pair * pair_launches / launches
         out.update({"traffic": traffic, "achieved": per_pair * pair_launches / t / 1e9,
                     "frac": per_pair * pair_launches / t / 1e9 / HBM_PEAK_GBS,
-                    "traffic_source": "profiles/hbm_traffic.json[frame_batch8:grid] / 8 pairs x pairs per launch "
-                                      "(tools/collect_counters.py: (2 x FETCH_SIZE + WRITE_SIZE) KB, separate --pmc passes)"})
+                    "traffic_source": f"profiles/hbm_traffic.json[frame_batch{int(epairs)}:grid] / {int(epairs)} pairs x pairs per launch "
+                                      "(tools/collect_counters.py: read requests by size + WRITE_SIZE, separate --pmc passes)"})
+        if e.get("rocprof_avg_launch_ns") and abs(pair_launches / launches - epairs) < 0.5:
+            t_k = float(e["rocprof_avg_launch_ns"]) * 1e-9
+            out["frac_range"] = {"hip_event_bracket": out["frac"], "rocprof_kernel_duration": per_pair * epairs / t_k / 1e9 / HBM_PEAK_GBS,
+                                 "rocprof_avg_launch_ms": t_k * 1e3}
         if v_pair:
             out["valu_issue_frac"] = v_pair * pair_launches / (N_SIMD * VALU_ISSUE_PER_SIMD * t)
     return out
@@ -323,29 +340,39 @@ def set_clouds_device(ctx, src_d, tgt_d):
     ctx.set_source_device(src_d.data_ptr(), src_d.data_ptr() + nq * es, src_d.data_ptr() + 2 * nq * es, nq)
 
 
-def timed_alignments(torch, ctx, params, steps, warmup, sync_all):
-    """W untimed + exactly K timed icpk_align calls; every 21st NN launch (one per alignment, the
-    position rotating) is bracketed by two HIP events on the context's stream."""
+def timed_alignments(torch, ctx, params, steps, warmup, sync_all, blocks=1):
+    """W untimed, then `blocks` timed regions of exactly K steps each, every region bracketed by sync_all(); a step =
+    icpk_reset_source (the pair back at its initial pose: three stream-ordered device copies, inside the timed region) +
+    icpk_align.  One NN launch per alignment (the position rotating over its sweeps) is bracketed by two HIP events on
+    the context's stream.  Returns the MEDIAN block's (elapsed, iterations, launches) -- one scheduler hiccup cannot
+    move the number -- plus the event totals over all blocks and every block's elapsed time."""
     params.profile = 0
     for _ in range(warmup):
+        ctx.reset_source()
         ctx.align(params)
     params.profile = 1
     params.profile_stride = params.max_iterations + 1
     gc.collect()
-    gc.disable()  # a generation-2 collection of the interpreter (tens of ms) must not land in the timed region
-    sync_all()
-    t0 = time.perf_counter()
+    gc.disable()  # a generation-2 collection of the interpreter (tens of ms) must not land in a timed region
     nn_ms = 0.0
-    nn_timed = nn_launches = iters_done = 0
-    for _ in range(steps):
-        T, st, rc = ctx.align(params)
-        nn_ms += st.nn_ms_total
-        nn_launches += st.nn_launches
-        nn_timed += st.nn_timed_launches
-        iters_done += st.iterations
-    sync_all()
-    elapsed = time.perf_counter() - t0
+    nn_timed = 0
+    per_block = []
+    for _ in range(blocks):
+        sync_all()
+        t0 = time.perf_counter()
+        nn_launches = iters_done = 0
+        for _ in range(steps):
+            ctx.reset_source()
+            T, st, rc = ctx.align(params)
+            nn_ms += st.nn_ms_total
+            nn_launches += st.nn_launches
+            nn_timed += st.nn_timed_launches
+            iters_done += st.iterations
+        sync_all()
+        per_block.append((time.perf_counter() - t0, iters_done, nn_launches))
     gc.enable()
+    elapsed, iters_done, nn_launches = sorted(per_block)[len(per_block) // 2]
+    timed_alignments.last_blocks = [round(b[0] * 1e3, 4) for b in per_block]
     return elapsed, iters_done, nn_launches, nn_timed, nn_ms
 
 
@@ -387,10 +414,12 @@ def bench_single(args, torch, dev, gpu_index):
     def sync_all():
         torch.cuda.synchronize()
 
-    elapsed, iters_done, nn_launches, nn_timed, nn_ms = timed_alignments(torch, ctx, params, args.steps, args.warmup, sync_all)
+    elapsed, iters_done, nn_launches, nn_timed, nn_ms = timed_alignments(torch, ctx, params, args.steps, args.warmup, sync_all,
+                                                                         blocks=args.blocks)
+    block_ms = list(timed_alignments.last_blocks)
     avg_nn_s = nn_ms / max(nn_timed, 1) / 1e3
-    timing = (f"two HIP events on the kernel's own stream around one K1 launch per alignment of the timed region, the "
-              f"position rotating over the {args.iters + 1} sweeps ({nn_timed} of {nn_launches} launches; includes ~4 us of "
+    timing = (f"two HIP events on the kernel's own stream around one K1 launch per alignment of the timed regions, the "
+              f"position rotating over the {args.iters + 1} sweeps ({nn_timed} of {nn_launches * args.blocks} launches; includes ~4 us of "
               "event/dispatch latency; the rocprofv3 --kernel-trace average of the same command is in profiles/)")
     phys, yard = roofline_blocks(args.workload, args.nn_mode, nq, nt, avg_nn_s, timing, KERNEL_NAMES[args.nn_mode])
     # per-stage device times from one extra, untimed alignment (events around every stage)
@@ -402,8 +431,10 @@ def bench_single(args, torch, dev, gpu_index):
         "metric": METRIC, "value": iters_done / elapsed, "unit": "iter/s", "n_gpus": 1, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
+        "timed_blocks": {"blocks": args.blocks, "steps_per_block": args.steps, "ms_each": block_ms,
+                         "reported": "the median block: value = its iterations / its wall time, ms_per_step = its wall time / K"},
         "config": {"workload": f"{args.workload}: ONE frame pair, {nq} source x {nt} target points, {args.iters} fixed ICP "
-                               f"iterations per step, solve={args.solve}, nn={args.nn_mode} (BASELINE configs[1]); the "
+                               f"iterations per step from the pair's initial pose, solve={args.solve}, nn={args.nn_mode} (BASELINE configs[1]); the "
                                f"N > 1 lines run configs[3] (64 such pairs) and scale against frame_batch below",
                    "frame_pairs_per_step": 1, "parallelism": "1 GPU"},
         "nn_mpoints_per_s": nn_launches * nq / elapsed / 1e6,

@@ -242,7 +242,7 @@ int prepare_pruned_target(icpk_ctx* ctx, NnBoxes& bx) {
 // all zero between two sorts (the scan hands it back zeroed); a sort that did not get as far as its scan --
 // a failed launch -- leaves it marked dirty, and the next one clears all of it first.
 int ensure_scan_buffers(icpk_ctx* ctx) {
-  const size_t bytes = ((size_t)GRID_MAX_CELLS + 1) * sizeof(int);
+  const size_t bytes = ((size_t)ctx->grid_max_cells + 1) * sizeof(int);
   if (!ctx->qcount) {
     ICPK_HIP(ctx, hipMalloc((void**)&ctx->qcount, bytes));
     ctx->qcount_dirty = true;
@@ -265,7 +265,7 @@ int prepare_grid_target(icpk_ctx* ctx) {
   if (!ctx->grid_info) ICPK_HIP(ctx, hipMalloc((void**)&ctx->grid_info, sizeof(GridInfo)));
   if (!ctx->grid_bounds)
     ICPK_HIP(ctx, hipMalloc((void**)&ctx->grid_bounds, (size_t)GRID_BOUNDS_PARTS * 6 * sizeof(float)));
-  if (!ctx->cell_start) ICPK_HIP(ctx, hipMalloc((void**)&ctx->cell_start, ((size_t)GRID_MAX_CELLS + 1) * sizeof(int)));
+  if (!ctx->cell_start) ICPK_HIP(ctx, hipMalloc((void**)&ctx->cell_start, ((size_t)ctx->grid_max_cells + 1) * sizeof(int)));
   if (nt > ctx->t4_cap) {
     if (ctx->t4) ICPK_HIP(ctx, hipFree(ctx->t4));
     if (ctx->o4) ICPK_HIP(ctx, hipFree(ctx->o4));
@@ -282,7 +282,7 @@ int prepare_grid_target(icpk_ctx* ctx) {
   rc = ensure_scan_buffers(ctx);
   if (rc) return rc;
   launch_grid_bounds(ctx->tgt.x(), ctx->tgt.y(), ctx->tgt.z(), nt, ctx->grid_bounds, ctx->stream);
-  launch_grid_info(ctx->grid_bounds, nt, ctx->grid_ppc, ctx->grid_xdiv, ctx->grid_info, ctx->stream);
+  launch_grid_info(ctx->grid_bounds, nt, ctx->grid_ppc, ctx->grid_xdiv, ctx->grid_max_cells, ctx->grid_info, ctx->stream);
   // counting sort of the targets by cell: slot within the cell by atomics (the order inside a
   // cell is irrelevant: candidates are merged lexicographically), cell starts by an exclusive
   // scan of the counts (entry ncells = Nt), scatter into the AoS copy
@@ -690,7 +690,7 @@ void replay_setup(const SetupRecorder& rec, hipStream_t s) {
       }
       case SK_LOOP_INIT: launch_loop_init(c.loop_init, s); break;
       case SK_BOUNDS: launch_grid_bounds(c.bounds.x, c.bounds.y, c.bounds.z, c.bounds.n, c.bounds.fb, s); break;
-      case SK_INFO: launch_grid_info(c.info.fb, c.info.n, c.info.ppc, c.info.xdiv, c.info.g, s); break;
+      case SK_INFO: launch_grid_info(c.info.fb, c.info.n, c.info.ppc, c.info.xdiv, c.info.max_cells, c.info.g, s); break;
       case SK_QSLOT: {
         const QslotArgs& a = c.qslot;
         launch_grid_qslot(a.x, a.y, a.z, a.n, a.gi, a.count, a.cell, a.slot, a.coarse, s);
@@ -759,6 +759,7 @@ static icpk_ctx* make_context(int device_id, const icpk_ctx* parent) {
     ctx->grid_ppc = parent->grid_ppc;
     ctx->grid_xdiv = parent->grid_xdiv;
     ctx->grid_slices = parent->grid_slices;
+    ctx->grid_max_cells = GRID_MAX_CELLS_SLOT;
     ctx->q_per_lane = parent->q_per_lane;
   }
   ctx->log_last = std::chrono::steady_clock::now();

@@ -102,7 +102,8 @@ struct icpk_ctx {
   // grid scan (ICPK_NN_GRID): cell table + AoS copy of the target sorted by cell
   icpk::GridInfo* grid_info = nullptr;
   float* grid_bounds = nullptr;
-  int* cell_start = nullptr;  // GRID_MAX_CELLS + 1
+  int* cell_start = nullptr;  // grid_max_cells + 1
+  int grid_max_cells = icpk::GRID_MAX_CELLS;  // capacity of cell_start / qcount / qstart (a frame-batch slot: GRID_MAX_CELLS_SLOT)
   float4* t4 = nullptr;
   float4* o4 = nullptr;      // the target in the CALLER's order as (x, y, z, 0): K2's gather of the matched point is one 16-byte load (valid while have_grid)
   float4* qm4 = nullptr;     // queries in scan order (x, y, z, original index)
@@ -130,7 +131,7 @@ struct icpk_ctx {
   // RCCL communicator of the frame-batch / query-sharded modes (icpk_comm.cpp); null until
   // icpk_comm_init_rccl
   struct icpk_comm_state* comm = nullptr;
-  int* qcount = nullptr;     // query counting sort by cell: counts and starts, GRID_MAX_CELLS + 1 each
+  int* qcount = nullptr;     // query counting sort by cell: counts and starts, grid_max_cells + 1 each
   int* qstart = nullptr;
   bool qcount_dirty = false; // a counting sort was cut short: clear the whole count table before the next one
   int* scan_bsum = nullptr;  // block sums of the cell-count scans (GRID_SCAN_BLOCKS ints)

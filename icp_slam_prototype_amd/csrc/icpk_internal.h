@@ -103,6 +103,10 @@ void launch_decimate(const float* x, const float* y, const float* z, int n, int 
 #define ICPK_GRID_MAX_CELLS_LOG2 23  // 3 tables of 32 MB per context; 22 clipped the cell edge of the dense clouds
 #endif
 constexpr int GRID_MAX_CELLS = 1 << ICPK_GRID_MAX_CELLS_LOG2;
+// the slots of the frame-batch mode (up to 32 child contexts) own smaller tables: Kinect-size pairs need ~0.9 M cells,
+// and 3 x 8 MB per slot instead of 3 x 32 MB keeps a 64-pair batch at 0.8 GB instead of 3.2 GB (a denser pair in a slot
+// merely gets a coarser grid: efficiency only)
+constexpr int GRID_MAX_CELLS_SLOT = 1 << 21;
 constexpr int GRID_BOUNDS_PARTS = 256;  // partial boxes of the bounds pass (6 floats each)
 struct GridInfo {
   float lo[3];  // finite lower corner of the target
@@ -116,7 +120,7 @@ struct GridInfo {
   int ncells_q;
 };
 void launch_grid_bounds(const float* x, const float* y, const float* z, int n, float* fb, hipStream_t s);
-void launch_grid_info(const float* fb, int n, float ppc, int xdiv, GridInfo* g, hipStream_t s);
+void launch_grid_info(const float* fb, int n, float ppc, int xdiv, int max_cells, GridInfo* g, hipStream_t s);
 void launch_grid_tscatter(const float* x, const float* y, const float* z, const int* tcell, const int* tslot,
                           const int* cell_start, int n, float4* t4, float4* o4, hipStream_t s);
 void launch_grid_qslot(const float* x, const float* y, const float* z, int n, const GridInfo* g, int* count, int* qcell,
@@ -328,6 +332,8 @@ struct InfoArgs {
   int nparts, n;
   float ppc;
   int xdiv;
+  int max_cells;  // capacity of this context's cell tables
+  int pad0;
 };
 struct QslotArgs {
   const float *x, *y, *z;

@@ -67,12 +67,12 @@ __global__ __launch_bounds__(1024) void grid_bounds_batch_kernel(const SetupBatc
 
 // cell edge: about `ppc` targets per occupied cell if the cloud is a surface whose area is
 // of the order of the bounding box's faces (a depth image is); never more than
-// GRID_MAX_CELLS cells.  Only efficiency depends on the choice.
+// the context's table capacity (GRID_MAX_CELLS; GRID_MAX_CELLS_SLOT for a frame-batch slot).  Only efficiency depends on the choice.
 // Cells are `xdiv` times finer along x, the axis the sorted order runs along: a query's cube
 // costs one contiguous range per (y, z) row whatever the x resolution, so finer x cells trim
 // the ranges to the cube (fewer candidates outside it) at no extra look-up.
 __device__ __forceinline__ void grid_info_body(const float* __restrict__ fbp, int nparts, int n, float ppc, int xdiv,
-                                               GridInfo* __restrict__ g) {
+                                               int max_cells, GridInfo* __restrict__ g) {
   // one wave: lane l merges the partial boxes l, l + 64, ...; xor butterfly; lane 0 goes on
   float fb[6];
 #pragma unroll
@@ -109,7 +109,7 @@ __device__ __forceinline__ void grid_info_body(const float* __restrict__ fbp, in
     nx = (int)(ext[0] / hx) + 1;
     ny = (int)(ext[1] / h) + 1;
     nz = (int)(ext[2] / h) + 1;
-    if ((long long)nx * ny * nz <= GRID_MAX_CELLS) break;
+    if ((long long)nx * ny * nz <= max_cells) break;
 #ifndef ICPK_GRID_GROW
 #define ICPK_GRID_GROW 1.06f  // (1.26 left up to half of the table unused: a cell edge 20 % longer than necessary)
 #endif
@@ -131,10 +131,10 @@ __device__ __forceinline__ void grid_info_body(const float* __restrict__ fbp, in
   g->ncells_q = g->nxq * ny * nz;
 }
 
-__global__ void grid_info_kernel(const InfoArgs a) { grid_info_body(a.fb, a.nparts, a.n, a.ppc, a.xdiv, a.g); }
+__global__ void grid_info_kernel(const InfoArgs a) { grid_info_body(a.fb, a.nparts, a.n, a.ppc, a.xdiv, a.max_cells, a.g); }
 __global__ void grid_info_batch_kernel(const SetupBatchOf<InfoArgs> b) {
   const InfoArgs& a = b.p[blockIdx.x];
-  grid_info_body(a.fb, a.nparts, a.n, a.ppc, a.xdiv, a.g);
+  grid_info_body(a.fb, a.nparts, a.n, a.ppc, a.xdiv, a.max_cells, a.g);
 }
 
 // The ONE mapping coordinate -> cell index along an axis, used for targets and for the
@@ -375,8 +375,8 @@ void launch_grid_bounds_batch(const SetupBatchOf<BoundsArgs>& b, int count, hipS
   for (int k = 0; k < count; ++k) m = b.p[k].nparts > m ? b.p[k].nparts : m;
   if (count > 0 && m > 0) hipLaunchKernelGGL(grid_bounds_batch_kernel, dim3(m, count), dim3(1024), 0, s, b);
 }
-void launch_grid_info(const float* fb, int n, float ppc, int xdiv, GridInfo* g, hipStream_t s) {
-  const InfoArgs a{fb, g, grid_bounds_parts(n), n, ppc, xdiv < 1 ? 1 : xdiv};
+void launch_grid_info(const float* fb, int n, float ppc, int xdiv, int max_cells, GridInfo* g, hipStream_t s) {
+  const InfoArgs a{fb, g, grid_bounds_parts(n), n, ppc, xdiv < 1 ? 1 : xdiv, max_cells < 64 ? 64 : max_cells, 0};
   ICPK_RECORD(SK_INFO, info, a)
   hipLaunchKernelGGL(grid_info_kernel, dim3(1), dim3(64), 0, s, a);
 }

@@ -4,8 +4,13 @@ For every (workload, NN kernel) bench.py reports a roofline for, run tools/one_a
 rocprofv3 in SEPARATE passes -- kernel trace + stats, then one --pmc pass per counter group
 (FETCH_SIZE and WRITE_SIZE do not fit one pass on gfx950; MI355X_MICROARCH.md, rocprofv3 PMC slots)
 -- and average every counter over the dispatches of the NN kernel (first sweeps in the proportion
-they occur in an alignment).  HBM bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024: the
-gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md (HBM section), WRITE_SIZE as read.
+they occur in an alignment).  HBM bytes per launch: reads = 128 x TCC_EA0_RDREQ_128B + 64 x TCC_EA0_RDREQ_64B +
+32 x TCC_EA0_RDREQ_32B (the L2's memory-side read requests by size), writes = WRITE_SIZE x 1024 (= 64 x WRREQ_64B +
+32 x the rest).  Calibrated on known byte counts in this kernel's access shapes (tools/microbench_traffic.hip,
+profiles/r03_traffic_calibration.txt): every read request on gfx950 is a 128-byte line -- a 64-byte gather by 4 lanes
+fetches 128, a 4-byte cell_start look-up fetches 128 -- which FETCH_SIZE tallies at 64 bytes, so 2 x FETCH_SIZE equals
+the request-size sum (kept as a cross-check); WRITE_SIZE is exact (32-byte sectors: a scattered 4- or 8-byte store
+costs 32 bytes, two adjacent 16-byte stores 33.6).
 
 Run on the GPU box:   python3 tools/collect_counters.py [--only key,key] [--tag r02]
 Outputs (tracked):    profiles/<tag>_<workload>_<mode>_counters.csv, profiles/<tag>_<workload>_<mode>_kernel_stats.csv,
@@ -29,8 +34,11 @@ JOBS = {  # key -> (one_align arguments, substring naming the NN kernel)
     "kinect640x480_dense:grid": (["--workload", "kinect640x480_dense", "--nn-mode", "grid"], "nn_grid_kernel"),
     "dense1m:grid": (["--workload", "dense1m", "--nn-mode", "grid", "--iters", "50", "--reps", "1"], "nn_grid_kernel"),
     "frame_batch8:grid": (["--batch", "8"], "nn_grid_batch_kernel"),
+    "frame_batch16:grid": (["--batch", "16"], "nn_grid_batch_kernel"),  # the launch shape of bench.py's frame_batch block (groups of 16)
+    "kinect_v2_512x424:grid": (["--workload", "kinect_v2_512x424", "--nn-mode", "grid"], "nn_grid_kernel"),
 }
-PASSES = [["FETCH_SIZE"], ["WRITE_SIZE"], ["SQ_INSTS_VALU", "SQ_WAVES", "SQ_INSTS_SALU"], ["SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_LDS"]]
+RD = ["TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_64B_sum", "TCC_EA0_RDREQ_128B_sum"]
+PASSES = [["FETCH_SIZE"], ["WRITE_SIZE"], RD, ["SQ_INSTS_VALU", "SQ_WAVES", "SQ_INSTS_SALU"], ["SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_LDS"]]
 
 
 def run(cmd, log, timeout):
@@ -47,7 +55,7 @@ def run(cmd, log, timeout):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
-    ap.add_argument("--tag", default="r02")
+    ap.add_argument("--tag", default="r03")
     ap.add_argument("--timeout", type=int, default=240)
     ap.add_argument("--mirror", default=os.path.join(ROOT, "gpurun_out", "profiles_new"),
                     help="second copy of every output (gpurun merges only gpurun_out/ back: copy it into profiles/)")
@@ -86,7 +94,7 @@ def main():
                      os.path.join(logdir, f"{slug}_pmc{i}.log"), a.timeout)
             print(key, "pmc", grp, "rc", rc, flush=True)
             if rc != 0:
-                ok = ok and i >= 2  # the traffic passes are mandatory, the instruction mix is not
+                ok = ok and i >= 3  # the traffic passes are mandatory, the instruction mix is not
                 continue
             for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
                 for r in csv.DictReader(open(f)):
@@ -107,11 +115,16 @@ def main():
             return s / n if n else None
 
         fetch_kb, write_kb = avg("FETCH_SIZE"), avg("WRITE_SIZE")
-        if fetch_kb is None or write_kb is None:
+        n32, n64, n128 = avg("TCC_EA0_RDREQ_32B_sum"), avg("TCC_EA0_RDREQ_64B_sum"), avg("TCC_EA0_RDREQ_128B_sum")
+        if fetch_kb is None or write_kb is None or n128 is None:
             continue
+        read_bytes = 128.0 * n128 + 64.0 * n64 + 32.0 * n32
         table[key] = {
             "kernel": kname, "fetch_size_kb": fetch_kb, "write_size_kb": write_kb,
-            "hbm_bytes_per_launch": (2.0 * fetch_kb + write_kb) * 1024.0,
+            "read_requests": {"32B": n32, "64B": n64, "128B": n128}, "read_bytes_per_launch": read_bytes,
+            "read_bytes_over_2x_fetch_size": read_bytes / (2.0 * fetch_kb * 1024.0) if fetch_kb else None,
+            "write_bytes_per_launch": write_kb * 1024.0,
+            "hbm_bytes_per_launch": read_bytes + write_kb * 1024.0,
             "valu_insts_per_launch": avg("SQ_INSTS_VALU"), "salu_insts_per_launch": avg("SQ_INSTS_SALU"),
             "waves_per_launch": avg("SQ_WAVES"), "vmem_rd_insts_per_launch": avg("SQ_INSTS_VMEM_RD"),
             "vmem_wr_insts_per_launch": avg("SQ_INSTS_VMEM_WR"), "lds_insts_per_launch": avg("SQ_INSTS_LDS"),
@@ -119,9 +132,10 @@ def main():
             "source": f"profiles/{a.tag}_{slug}_counters.csv, profiles/{a.tag}_{slug}_kernel_stats.csv (tools/collect_counters.py)",
         }
         print(key, json.dumps(table[key]), flush=True)
-    table["_note"] = ("written by tools/collect_counters.py; hbm_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 averaged "
-                      "over the NN kernel's dispatches, separate rocprofv3 --pmc passes; FETCH_SIZE doubled per the gfx950 "
-                      "correction of MI355X_MICROARCH.md (HBM section); WRITE_SIZE as read")
+    table["_note"] = ("written by tools/collect_counters.py; hbm_bytes_per_launch = 128*RDREQ_128B + 64*RDREQ_64B + 32*RDREQ_32B "
+                      "(TCC_EA0 read requests by size) + WRITE_SIZE*1024, averaged over the NN kernel's dispatches, separate "
+                      "rocprofv3 --pmc passes; calibration of these counters on known byte counts in the kernel's access shapes: "
+                      "profiles/r03_traffic_calibration.txt (tools/pmc_traffic.sh); 2 x FETCH_SIZE is kept as a cross-check")
     json.dump(table, open(tfile, "w"), indent=1, sort_keys=True)
     print("wrote", tfile)
     if a.mirror:
