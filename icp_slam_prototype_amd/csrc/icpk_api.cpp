@@ -161,27 +161,28 @@ int ensure_sort_buffers(icpk_ctx* ctx, int n) {
     ICPK_HIP(ctx, hipMalloc((void**)&ctx->sort_vals, (size_t)cap * sizeof(int)));
     ctx->sort_cap = cap;
   }
-  const size_t need = sort_temp_bytes(n);
-  if (need > ctx->sort_temp_bytes) {
-    if (ctx->sort_temp) ICPK_HIP(ctx, hipFree(ctx->sort_temp));
-    ctx->sort_temp = nullptr;
-    ctx->sort_temp_bytes = 0;
-    ICPK_HIP(ctx, hipMalloc(&ctx->sort_temp, need));
-    ctx->sort_temp_bytes = need;
-  }
   if (!ctx->bounds) ICPK_HIP(ctx, hipMalloc((void**)&ctx->bounds, 6 * sizeof(float)));
   return ICPK_OK;
 }
 
-// Morton order of `c` (keys from the target's bounds) -> perm_out[k] = index of the k-th point
+int ensure_scan_buffers(icpk_ctx* ctx);
+
+// Morton order of `c` (cells of the target's bounding box) -> perm_out[k] = index of the k-th point; the sorted keys
+// land in sort_keys[sort_cap ...), the unsorted ones stay in sort_keys[0 ... n)
 int enqueue_morton_order(icpk_ctx* ctx, const Cloud& c, int* perm_out) {
   int rc = ensure_sort_buffers(ctx, c.n);
   if (rc) return rc;
+  rc = ensure_scan_buffers(ctx);
+  if (rc) return rc;
+  if (!ctx->morton_table) ICPK_HIP(ctx, hipMalloc((void**)&ctx->morton_table, sizeof(GridInfo)));
   unsigned* ka = ctx->sort_keys;
   unsigned* kb = ctx->sort_keys + ctx->sort_cap;
-  launch_morton(c.x(), c.y(), c.z(), c.n, ctx->bounds, ka, ctx->sort_vals, ctx->stream);
-  if (launch_sort_pairs(ctx->sort_temp, ctx->sort_temp_bytes, ka, kb, ctx->sort_vals, perm_out, c.n, ctx->stream) != 0)
-    return fail(ctx, ICPK_E_HIP, "rocprim::radix_sort_pairs failed");
+  const int bits = ctx->grid_max_cells >= (1 << 21) + 1 ? 7 : 6;  // 8^bits cells + 1 bin + 1 must fit the count table
+  ctx->qcount_dirty = true;
+  launch_morton_order(c.x(), c.y(), c.z(), c.n, ctx->bounds, bits, ka, ctx->sort_vals, ctx->qcount, ctx->qstart, ctx->scan_bsum,
+                      ctx->morton_table, kb, perm_out, ctx->stream);
+  ICPK_HIP(ctx, hipGetLastError());
+  ctx->qcount_dirty = false;
   return ICPK_OK;
 }
 
@@ -829,7 +830,7 @@ void icpk_destroy(icpk_ctx* ctx) {
                        ctx->batch_t0[1], ctx->batch_t1[0], ctx->batch_t1[1]})
     if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : ctx->events) (void)hipEventDestroy(e);
-  void* dev[] = {ctx->qcount, ctx->qstart, ctx->scan_bsum, ctx->qm4, ctx->sp_in, ctx->sp_out, ctx->rec, ctx->grid_info, ctx->grid_bounds, ctx->cell_start, ctx->t4, ctx->o4, ctx->best_m, ctx->seed_m, ctx->st_pooled ? nullptr : (void*)ctx->st_dev, ctx->sorted.base, ctx->tkeys, ctx->tperm, ctx->qperm, ctx->bounds, ctx->sort_keys, ctx->sort_vals, ctx->sort_temp,
+  void* dev[] = {ctx->qcount, ctx->qstart, ctx->scan_bsum, ctx->qm4, ctx->sp_in, ctx->sp_out, ctx->rec, ctx->grid_info, ctx->grid_bounds, ctx->cell_start, ctx->t4, ctx->o4, ctx->best_m, ctx->seed_m, ctx->st_pooled ? nullptr : (void*)ctx->st_dev, ctx->sorted.base, ctx->tkeys, ctx->tperm, ctx->qperm, ctx->bounds, ctx->sort_keys, ctx->sort_vals, ctx->morton_table,
                  ctx->nrm.base, ctx->boxes, ctx->dec.base, ctx->tgt.base, ctx->src0.base, ctx->src.base, ctx->best,      ctx->seed,     ctx->idx,
                  ctx->dist,     ctx->partial,   ctx->pcount,   ctx->red_out,   ctx->depth_dev, ctx->depth_flt, ctx->ks_buf, ctx->bp_counts};
   for (void* p : dev)

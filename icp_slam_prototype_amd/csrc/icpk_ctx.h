@@ -54,8 +54,7 @@ struct icpk_ctx {
   unsigned* sort_keys = nullptr;  // 2 x sort_cap
   int* sort_vals = nullptr;       // sort_cap
   int sort_cap = 0;
-  void* sort_temp = nullptr;
-  size_t sort_temp_bytes = 0;
+  icpk::GridInfo* morton_table = nullptr;  // device: the table size of the Morton counting sort (pruned scan), for launch_grid_scan
   bool have_seed = false;  // `best` holds matches of a previous sweep of the same clouds
   nn_key_t* best = nullptr;
   nn_key_t* seed = nullptr;

@@ -78,11 +78,10 @@ struct NnBoxes {
 
 // kernels_sort.hip
 void launch_bounds(const float* tbox, int tbox_stride, int ntiles, float* bounds, hipStream_t s);
-void launch_morton(const float* x, const float* y, const float* z, int n, const float* bounds, unsigned* keys, int* vals,
-                   hipStream_t s);
-size_t sort_temp_bytes(int n);
-int launch_sort_pairs(void* temp, size_t temp_bytes, const unsigned* keys_in, unsigned* keys_out, const int* vals_in,
-                      int* vals_out, int n, hipStream_t s);
+struct GridInfo;
+void launch_morton_order(const float* x, const float* y, const float* z, int n, const float* bounds, int bits,
+                         unsigned* keys, int* slot, int* count, int* start, int* bsum, GridInfo* table,
+                         unsigned* keys_out, int* perm_out, hipStream_t s);
 void launch_gather_planes(const float* x, const float* y, const float* z, const int* perm, int n, int n_pad, float pad,
                           float* ox, float* oy, float* oz, int* perm_pad, hipStream_t s);
 void launch_nn_filtered(const NnArgs& a, const nn_key_t* seed, int seed_scale, int q_per_lane, hipStream_t s);

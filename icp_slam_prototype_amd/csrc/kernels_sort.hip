@@ -2,16 +2,19 @@
 //
 // the reference's own planned replacement for the brute-force
 // scan is a voxel lookup (icp.cpp:347-486, map.hpp:9-17).  Here the same idea serves
-// an EXACT search: targets are re-ordered along a 30-bit Morton curve so that every
-// run of 128 consecutive points is a compact 3-D cluster with a tight bounding box;
-// the NN kernel skips boxes that are out of reach and still returns the brute-force
-// result (original indices are carried along for the lowest-index tie rule).
+// an EXACT search: targets are re-ordered along a Morton curve so that every run of
+// 128 consecutive points is a compact 3-D cluster with a tight bounding box; the NN
+// kernel skips boxes that are out of reach and still returns the brute-force result
+// (original indices are carried along for the lowest-index tie rule).
 //
-// The sort itself is a set-up step (once per target cloud / per alignment), done with
-// rocPRIM's device radix sort; everything on the per-iteration path is hand-written.
+// The sort is the same hand-written counting sort the grid scan uses (kernels_grid.hip: slot inside
+// the bin by atomics, device-sized exclusive scan of the counts, scatter), over the cells of a
+// 2^b x 2^b x 2^b lattice of the cloud's bounding box taken in Morton order, b = 7 or 6 bits per
+// axis (whatever the context's count table holds), non-finite points in a last bin of their own.
+// The order INSIDE a cell is whatever the atomics make it: only the tightness of the boxes, never
+// a result, depends on it.  (Rounds 1-2 called rocPRIM's radix sort on 30-bit codes here: the one
+// library call of the code base, in a set-up step of a non-default mode; gone in round 3.)
 #include <cstring>
-
-#include <rocprim/device/device_radix_sort.hpp>
 
 #include "icpk_internal.h"
 
@@ -46,54 +49,67 @@ __device__ __forceinline__ unsigned spread10(unsigned v) {  // 10 bits -> every 
   return v;
 }
 
-// key = 30-bit Morton code of the point inside `bounds`; non-finite points (padding)
-// get 0xffffffff and sort last.  vals = identity.
-__global__ void morton_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z,
-                              int n, const float* __restrict__ bounds, unsigned* __restrict__ keys,
-                              int* __restrict__ vals) {
+// key = Morton code (bits per axis: `bits`) of the point's lattice cell inside `bounds`; non-finite
+// points (padding) get the bin after the last cell, 8^bits, and sort last.  slot = arrival number
+// inside the bin.
+__global__ void morton_slot_kernel(const float* __restrict__ x, const float* __restrict__ y, const float* __restrict__ z,
+                                   int n, const float* __restrict__ bounds, int bits, unsigned* __restrict__ keys,
+                                   int* __restrict__ slot, int* __restrict__ count) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const float p[3] = {x[i], y[i], z[i]};
+  const float top = (float)((1 << bits) - 1);
   unsigned q[3];
   bool finite = true;
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     const float lo = bounds[c], hi = bounds[3 + c];
     const float ext = hi - lo;
-    const float s = ext > 0.f ? 1023.0f / ext : 0.f;
+    const float s = ext > 0.f ? top / ext : 0.f;
     float f = (p[c] - lo) * s;
     finite = finite && (p[c] - p[c] == 0.f);
-    f = __builtin_fminf(__builtin_fmaxf(f, 0.f), 1023.f);  // NaN -> 0
+    f = __builtin_fminf(__builtin_fmaxf(f, 0.f), top);  // NaN -> 0
     q[c] = (unsigned)f;
   }
-  keys[i] = finite ? (spread10(q[0]) | (spread10(q[1]) << 1) | (spread10(q[2]) << 2)) : 0xffffffffu;
-  vals[i] = i;
+  const unsigned k = finite ? (spread10(q[0]) | (spread10(q[1]) << 1) | (spread10(q[2]) << 2)) : (1u << (3 * bits));
+  keys[i] = k;
+  slot[i] = atomicAdd(&count[k], 1);
+}
+
+__global__ void morton_scatter_kernel(const unsigned* __restrict__ keys, const int* __restrict__ slot,
+                                      const int* __restrict__ start, int n, unsigned* __restrict__ keys_out,
+                                      int* __restrict__ perm_out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const unsigned k = keys[i];
+  const int pos = start[k] + slot[i];
+  keys_out[pos] = k;
+  perm_out[pos] = i;
+}
+
+// the table size launch_grid_scan reads from a GridInfo on the device: 8^bits cells + the bin of the non-finite points
+__global__ void morton_table_kernel(GridInfo* __restrict__ g, int bits) {
+  if (threadIdx.x == 0) {
+    g->ncells = (1 << (3 * bits)) + 1;
+    g->ncells_q = g->ncells;
+  }
 }
 
 void launch_bounds(const float* tbox, int tbox_stride, int ntiles, float* bounds, hipStream_t s) {
   hipLaunchKernelGGL(bounds_kernel, dim3(1), dim3(256), 0, s, tbox, tbox_stride, ntiles, bounds);
 }
 
-void launch_morton(const float* x, const float* y, const float* z, int n, const float* bounds, unsigned* keys, int* vals,
-                   hipStream_t s) {
+// keys_out / perm_out: the points by Morton cell; keys: the unsorted keys (kept: the queries' keys seed the first
+// sweep); count: the context's zeroed count table (handed back zeroed), start / bsum: scan outputs / scratch
+void launch_morton_order(const float* x, const float* y, const float* z, int n, const float* bounds, int bits,
+                         unsigned* keys, int* slot, int* count, int* start, int* bsum, GridInfo* table,
+                         unsigned* keys_out, int* perm_out, hipStream_t s) {
   if (n <= 0) return;
-  hipLaunchKernelGGL(morton_kernel, dim3((n + 255) / 256), dim3(256), 0, s, x, y, z, n, bounds, keys, vals);
+  hipLaunchKernelGGL(morton_table_kernel, dim3(1), dim3(64), 0, s, table, bits);
+  hipLaunchKernelGGL(morton_slot_kernel, dim3((n + 255) / 256), dim3(256), 0, s, x, y, z, n, bounds, bits, keys, slot, count);
+  launch_grid_scan(count, start, bsum, table, 0, s);
+  hipLaunchKernelGGL(morton_scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, s, keys, slot, start, n, keys_out, perm_out);
 }
-
-size_t sort_temp_bytes(int n) {
-  size_t bytes = 0;
-  (void)rocprim::radix_sort_pairs(nullptr, bytes, (unsigned*)nullptr, (unsigned*)nullptr, (int*)nullptr, (int*)nullptr,
-                                  (size_t)n, 0, 32, (hipStream_t) nullptr);
-  return bytes;
-}
-
-// stable LSD radix sort: equal Morton codes keep their original relative order
-int launch_sort_pairs(void* temp, size_t temp_bytes, const unsigned* keys_in, unsigned* keys_out, const int* vals_in,
-                      int* vals_out, int n, hipStream_t s) {
-  return (int)rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0, 32, s);
-}
-
-
 
 // out[k] = in[perm[k]] for k < n, pad beyond (planes are NN_TILE-padded)
 __global__ void gather_planes_kernel(const float* __restrict__ x, const float* __restrict__ y,
