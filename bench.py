@@ -799,31 +799,62 @@ def bench_frame_batch(args, torch, dist, rank, world, dev, cdev, gpu_index, rehe
     ctx.close()
 
 
-def bench_query_sharded(args, torch, dist, rank, world, dev, cdev, gpu_index):
-    """One frame pair, queries split over the ranks (batch.align_query_sharded): per iteration
-    every rank runs K1/K2 on its slice, then ONE all-reduce of 19 sums + count (160 bytes) and a
-    replicated 3x3 solve.  The loop is host-driven (the collective sits between K2 and the
-    solve), so this mode pays one stream sync + one collective latency per iteration."""
+def bench_query_sharded(args, torch, dist, rank, world, dev, cdev, gpu_index, rehearsal=False):
+    """One frame pair, queries split over the ranks.  Default: the C ABI's device-side loop (icpk_align_query_sharded:
+    per iteration the sweep and the reduction on the rank's slice, ONE in-stream ncclAllReduce of 20 doubles, the
+    replicated loop step on the reduced sums; no host round trip), the target broadcast through
+    icpk_comm_broadcast_target.  Falls back -- saying so in the line -- to the host-driven loop over torch.distributed
+    (one stream sync + one collective per iteration) if RCCL cannot be initialised through the C ABI."""
     from icp_slam_prototype_amd import batch, binding
 
-    comm = batch.TorchComm(dist, cdev)
     w = make_workload(args.workload, 2)
-    tgt = comm.broadcast_cloud(w["target"] if rank == 0 else None, 0).cpu().numpy()
     nq_total = w["source"].shape[1]
     s0, cnt = batch.partition(nq_total, world, rank)
     src = np.ascontiguousarray(w["source"][:, s0:s0 + cnt])
     ctx = binding.Context(gpu_index)
-    ctx.set_target(tgt)
-    ctx.set_source(src)
-    modes = {"exact": binding.NN_EXACT, "filtered": binding.NN_FILTERED, "pruned": binding.NN_PRUNED, "grid": binding.NN_GRID}
-    steps = batch.ContextSteps(ctx, modes[args.nn_mode])
     solve = {"reference": 0, "kabsch": 1}.get(args.solve)
     if solve is None:
         raise SystemExit("--shard queries supports --solve reference|kabsch")
+    comm = comm_err = None
+    if args.comm in ("auto", "icpk") and (not rehearsal or (os.environ.get("ICPK_TEST_HOOKS") == "1" and os.environ.get("ICPK_RCCL_LIB"))):
+        def exchange(uid):
+            box = [uid]
+            dist.broadcast_object_list(box, src=0)
+            return box[0]
 
-    def one_step():
-        ctx.reset_source()
-        return batch.align_query_sharded(steps, comm, max_iterations=args.iters, solve=solve, fixed_iterations=True)
+        try:
+            comm = batch.RcclComm(ctx, rank, world, exchange)
+        except Exception as e:  # noqa: BLE001
+            if args.comm == "icpk":
+                raise
+            comm_err = repr(e)
+    ok = torch.tensor([1 if comm is not None else 0], device=cdev)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    device_loop = int(ok.item()) == 1 and args.nn_mode == "grid"
+    if device_loop:
+        if rank == 0:
+            ctx.set_target(w["target"])
+        comm.broadcast_target(0)  # RCCL broadcast of the target cloud over xGMI (north_star)
+        ctx.set_source(src)
+        nt = ctx.target_size
+        params = binding.default_params(max_iterations=args.iters, solve=solve, fixed_iterations=1)
+
+        def one_step():
+            return comm.align_query_sharded(params=params)
+    else:
+        if comm is not None:
+            comm.close()
+        comm = batch.TorchComm(dist, cdev)
+        tgt = comm.broadcast_cloud(w["target"] if rank == 0 else None, 0).cpu().numpy()
+        nt = tgt.shape[1]
+        ctx.set_target(tgt)
+        ctx.set_source(src)
+        modes = {"exact": binding.NN_EXACT, "filtered": binding.NN_FILTERED, "pruned": binding.NN_PRUNED, "grid": binding.NN_GRID}
+        steps = batch.ContextSteps(ctx, modes[args.nn_mode])
+
+        def one_step():
+            ctx.reset_source()
+            return batch.align_query_sharded(steps, comm, max_iterations=args.iters, solve=solve, fixed_iterations=True)
 
     for _ in range(args.warmup):
         one_step()
@@ -845,10 +876,16 @@ def bench_query_sharded(args, torch, dist, rank, world, dev, cdev, gpu_index):
             "metric": METRIC, "value": iters / elapsed, "unit": "iter/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {nq_total} source x {tgt.shape[1]} target points, {args.iters} "
+            "config": {"workload": f"{args.workload}: {nq_total} source x {nt} target points, {args.iters} "
                                    f"fixed ICP iterations per step, solve={args.solve}, nn={args.nn_mode}",
                        "parallelism": f"query-sharded x{world}, 1 all-reduce(160 B)/iteration"},
+            "loop": ("device-side (icpk_align_query_sharded): in-stream ncclAllReduce between K2 and the replicated loop step, "
+                     "no host round trip per iteration") if device_loop else
+                    "host-driven over torch.distributed: one stream sync + one collective per iteration",
+            "collectives": comm.kind, "collectives_fallback_reason": comm_err,
             "nn_mpoints_per_s": iters * nq_total / elapsed / 1e6}))
+    if isinstance(comm, batch.RcclComm):
+        comm.close()
     ctx.close()
 
 
@@ -889,7 +926,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     try:
         if args.shard == "queries":
-            bench_query_sharded(args, torch, dist, rank, world, dev, cdev, gpu_index)
+            bench_query_sharded(args, torch, dist, rank, world, dev, cdev, gpu_index, rehearsal)
         else:
             bench_frame_batch(args, torch, dist, rank, world, dev, cdev, gpu_index, rehearsal)
         dist.barrier()

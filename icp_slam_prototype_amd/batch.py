@@ -121,6 +121,13 @@ class RcclComm:
     def allreduce_sums(self, sums, count):
         return self.ctx.comm_allreduce_sums(sums, count)
 
+    def align_query_sharded(self, params=None, **kw):
+        """the device-side query-sharded loop (icpk_align_query_sharded): the context's source is this rank's slice of
+        the queries, the target the same on every rank; one in-stream all-reduce per iteration.
+        Returns (T, iterations, total pairs, mse, status) like align_query_sharded below."""
+        T, st, rc = self.ctx.align_query_sharded(params, **kw)
+        return T, st.iterations, st.final_pairs, st.final_mse, rc
+
     def barrier(self):
         self.ctx.comm_barrier()
 

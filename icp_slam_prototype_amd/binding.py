@@ -38,7 +38,7 @@ SYMBOLS = [
     "icpk_associate_keypoints", "icpk_filter_depth_image", "icpk_backproject_filtered", "icpk_backproject_pair",
     "icpk_comm_unique_id", "icpk_comm_init_rccl", "icpk_comm_destroy", "icpk_comm_rank", "icpk_comm_world",
     "icpk_comm_partition", "icpk_comm_broadcast_target", "icpk_comm_gather_results", "icpk_comm_allreduce_sums",
-    "icpk_comm_barrier",
+    "icpk_comm_barrier", "icpk_align_query_sharded",
 ]
 
 
@@ -177,6 +177,7 @@ def load():
     lib.icpk_comm_gather_results.argtypes = [C.c_void_p, fp, C.POINTER(Stats), C.c_int32, C.c_int32, fp, fp]
     lib.icpk_comm_allreduce_sums.argtypes = [C.c_void_p, dp, C.c_int32, C.POINTER(C.c_int64)]
     lib.icpk_comm_barrier.argtypes = [C.c_void_p]
+    lib.icpk_align_query_sharded.argtypes = [C.c_void_p, C.POINTER(Params), fp, C.POINTER(Stats)]
     _lib = lib
     return lib
 
@@ -506,6 +507,16 @@ class Context:
         T = np.zeros(16, np.float32)
         st = Stats()
         rc = self._chk(self._lib.icpk_align(self._h, C.byref(p), _fp(T), C.byref(st)))
+        return T.reshape(4, 4), st, rc
+
+    def align_query_sharded(self, params=None, **kw):
+        """One pair, queries sharded over the communicator's ranks (collective call): this context's source is the
+        rank's slice, the target is the same everywhere; one in-stream all-reduce of 20 doubles per iteration, no host
+        round trip.  Returns (T, stats, rc), identical on every rank."""
+        p = params if params is not None else default_params(**kw)
+        T = np.zeros(16, np.float32)
+        st = Stats()
+        rc = self._chk(self._lib.icpk_align_query_sharded(self._h, C.byref(p), _fp(T), C.byref(st)))
         return T.reshape(4, 4), st, rc
 
     def align_batch(self, pairs, params=None, associations=False, **kw):

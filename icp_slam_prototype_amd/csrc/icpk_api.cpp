@@ -1242,6 +1242,71 @@ static int align_device_loop(icpk_ctx* ctx, const icpk_params* p, float T_out[16
   return rc;
 }
 
+// Query-sharded alignment of ONE pair over the ranks of the context's communicator ("single huge
+// pair"; the frame-pair formulation icp.cpp:541-563 with the queries split): the target is the same on every rank
+// (icpk_comm_broadcast_target), the source is this rank's slice of the queries.  The whole loop is enqueued: per
+// iteration the grid sweep (K3 fused) and K2 on the slice, the canonical second tree stage, ONE in-stream float64
+// all-reduce of the 19 sums + the pair count (160 bytes), and the loop step on the reduced sums -- replicated, so
+// every rank applies the same transform, takes the same exit and returns the same T.  No host round trip and no
+// host copy per iteration (the host-driven loop of round 2 paid a stream sync + two staging copies each).
+// Results agree with icpk_align on the whole pair to ~1e-6 on T (the sums of the ranks are added by the collective:
+// another order than the single-GPU canonical tree); with one rank they are bit-identical.
+int icpk_align_query_sharded(icpk_ctx* ctx, const icpk_params* p, float T_out[16], icpk_stats* stats) {
+  int rc = check_ready(ctx);
+  if (rc) return rc;
+  if (!p || !T_out) return ICPK_E_ARG;
+  if (!ctx->comm) return fail(ctx, ICPK_E_NOT_SET, "icpk_comm_init_rccl has not been called");
+  if (p->solve != ICPK_SOLVE_REFERENCE && p->solve != ICPK_SOLVE_KABSCH)
+    return fail(ctx, ICPK_E_ARG, "the query-sharded loop supports the reference and Kabsch flavours");
+  if (p->max_iterations < 0 || p->max_iterations > LOOP_MAX_ITER) return fail(ctx, ICPK_E_ARG, "max_iterations out of range");
+  ICPK_HIP(ctx, hipSetDevice(ctx->device));
+  for (int k = 0; k < 16; ++k) T_out[k] = (k % 5 == 0) ? 1.f : 0.f;
+  if (stats) std::memset(stats, 0, sizeof(*stats));
+  icpk_params q = *p;
+  q.nn_mode = ICPK_NN_GRID;
+  rc = copy_src0_to_src(ctx);  // like icpk_align: the alignment starts from the source as set / committed
+  if (rc) return rc;
+  ctx->have_seed = false;
+  ctx->have_qperm = false;
+  ctx->trace_R.clear();
+  ctx->trace_t.clear();
+  ctx->trace_mse.clear();
+  ctx->trace_pairs.clear();
+  struct Guard {
+    icpk_ctx* c;
+    ~Guard() { device_loop_disarm(c); }
+  } guard{ctx};
+  rc = device_loop_begin(ctx, &q, false);
+  if (rc) return rc;
+  ctx->loop_nact = NSUM;  // both flavours through the full 19 sums: one message shape
+  const int B = red_blocks(ctx->src.n);
+  auto sweep = [&]() -> int {
+    // (an empty slice still takes part: its sums are zero)
+    int r = enqueue_nn(ctx, ICPK_NN_GRID);
+    if (r) return r;
+    r = enqueue_reduce(ctx, q.max_nn_dist);
+    if (r) return r;
+    launch_reduce_final_shard(ctx->partial, ctx->pcount, B, ctx->red_out, ctx->st_dev, ctx->stream);
+    return icpk_comm_allreduce_device(ctx, ctx->red_out, NSUM + 1);
+  };
+  rc = sweep();
+  for (int i = 0; rc == ICPK_OK && i < q.max_iterations; ++i) {
+    launch_loop_step(ctx->red_out, nullptr, -1, NSUM, ctx->st_dev, 0, ctx->stream);
+    rc = sweep();
+  }
+  if (rc) {
+    (void)hipStreamSynchronize(ctx->stream);
+    return rc;
+  }
+  launch_loop_step(ctx->red_out, nullptr, -1, NSUM, ctx->st_dev, 1, ctx->stream);
+  if (loop_rec(ctx))
+    launch_grid_unpack(ctx->qm4, ctx->rec, ctx->src.n, ctx->src.x(), ctx->src.y(), ctx->src.z(), ctx->best, ctx->stream);
+  ICPK_HIP(ctx, hipGetLastError());
+  ICPK_HIP(ctx, hipMemcpyAsync(ctx->st_host, ctx->st_dev, sizeof(LoopState), hipMemcpyDeviceToHost, ctx->stream));
+  ICPK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return device_loop_finish(ctx, &q, T_out, stats);
+}
+
 int icpk_transform_target(icpk_ctx* ctx, const float R[9], const float t[3]) {
   if (!ctx || !R || !t) return ICPK_E_ARG;
   if (!ctx->have_tgt) return fail(ctx, ICPK_E_NOT_SET, "target cloud not set");

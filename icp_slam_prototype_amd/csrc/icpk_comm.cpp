@@ -132,6 +132,15 @@ void shard(int n, int world, int rank, int& start, int& count) {
 
 }  // namespace
 
+// n float64 values on the device, summed over the ranks in place, ENQUEUED on the context's stream: no host copy, no
+// host wait (the query-sharded device loop calls this once per iteration between K2 and the loop step)
+int icpk_comm_allreduce_device(icpk_ctx* ctx, double* dev, int n) {
+  int rc = need_comm(ctx);
+  if (rc) return rc;
+  ICPK_RCCL(ctx, rccl()->AllReduce(dev, dev, (size_t)n, ncclFloat64, ncclSum, ctx->comm->comm, ctx->stream));
+  return ICPK_OK;
+}
+
 void icpk_comm_release(icpk_ctx* ctx) {
   if (!ctx || !ctx->comm) return;
   icpk_comm_state* c = ctx->comm;

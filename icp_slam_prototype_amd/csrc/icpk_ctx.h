@@ -165,3 +165,4 @@ int icpk_host_ensure_cloud(icpk_ctx* ctx, icpk::Cloud& c, int n);
 // pad it and drop everything derived from the previous target
 int icpk_host_target_replaced(icpk_ctx* ctx);
 void icpk_comm_release(icpk_ctx* ctx);  // called by icpk_destroy
+int icpk_comm_allreduce_device(icpk_ctx* ctx, double* dev, int n);  // in-stream sum over the ranks (icpk_comm.cpp)

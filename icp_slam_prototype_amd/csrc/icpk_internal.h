@@ -221,6 +221,10 @@ void launch_loop_step(const double* partial, const int* pcount, int nblocks, int
 void launch_loop_step_batch(const StepBatch& b, int count, int nsum, int stats_only, hipStream_t s);
 void launch_transform_state(float* x, float* y, float* z, int n, const LoopState* st, hipStream_t s);
 void launch_reduce_final(const double* partial, const int* pcount, int nblocks, int nsum, double* out, hipStream_t s);
+// query-sharded loop: NSUM sums + the count as a double into out[0 .. NSUM]; launch_loop_step with nblocks = -1 then
+// takes the (all-reduced) sums from there
+void launch_reduce_final_shard(const double* partial, const int* pcount, int nblocks, double* out, const LoopState* st,
+                               hipStream_t s);
 
 // kernels_reduce.hip
 // partial: [NSUM_MAX][RED_MAX_BLOCKS] doubles (sum-major: stage 2 reads it coalesced), pcount: [RED_MAX_BLOCKS] ints,

@@ -56,25 +56,37 @@ __device__ __forceinline__ void tree_stage2(const double* __restrict__ partial, 
   }
 }
 
+// count_as_double: the pair count as a float64 in out[NS] (exact below 2^53) instead of an int64 -- the query-sharded
+// loop all-reduces sums and count in ONE float64 message; st != nullptr: a launch inside a device loop (no-op once
+// the loop has exited)
 template <int NS>
 __global__ __launch_bounds__(256) void reduce_final_kernel(const double* __restrict__ partial,
                                                            const int* __restrict__ pcount, int nblocks,
-                                                           double* __restrict__ out) {
+                                                           double* __restrict__ out, int count_as_double,
+                                                           const LoopState* __restrict__ st) {
+  if (st && st->done) return;
   double sums[NS];
   long long count = 0;
   tree_stage2<NS>(partial, pcount, nblocks, sums, count);
   if (threadIdx.x == 0) {
 #pragma unroll
     for (int s = 0; s < NS; ++s) out[s] = sums[s];
-    reinterpret_cast<long long*>(out)[NS] = count;
+    if (count_as_double)
+      out[NS] = (double)count;
+    else
+      reinterpret_cast<long long*>(out)[NS] = count;
   }
 }
 
 void launch_reduce_final(const double* partial, const int* pcount, int nblocks, int nsum, double* out, hipStream_t s) {
   if (nsum == NP2L)
-    hipLaunchKernelGGL(reduce_final_kernel<NP2L>, dim3(1), dim3(256), 0, s, partial, pcount, nblocks, out);
+    hipLaunchKernelGGL(reduce_final_kernel<NP2L>, dim3(1), dim3(256), 0, s, partial, pcount, nblocks, out, 0, nullptr);
   else
-    hipLaunchKernelGGL(reduce_final_kernel<NSUM>, dim3(1), dim3(256), 0, s, partial, pcount, nblocks, out);
+    hipLaunchKernelGGL(reduce_final_kernel<NSUM>, dim3(1), dim3(256), 0, s, partial, pcount, nblocks, out, 0, nullptr);
+}
+void launch_reduce_final_shard(const double* partial, const int* pcount, int nblocks, double* out, const LoopState* st,
+                               hipStream_t s) {
+  hipLaunchKernelGGL(reduce_final_kernel<NSUM>, dim3(1), dim3(256), 0, s, partial, pcount, nblocks, out, 1, st);
 }
 
 __device__ void compose_rt(const float Rf[9], const float tf[3], double Tk[12]) {
@@ -114,7 +126,17 @@ __device__ __forceinline__ void loop_step_body(const double* __restrict__ partia
   STEP_STAMP(i, 0);
   double sums[NS];
   long long npairs = 0;
-  tree_stage2<NS, NACT>(partial, pcount, nblocks, sums, npairs);  // sums [NACT..NS) read as 0
+  if (nblocks < 0) {
+    // query-sharded loop: `partial` holds the sums of ALL ranks, already reduced (this rank's canonical tree, then one
+    // float64 all-reduce over the ranks): NS doubles + the pair count as a double
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int s = 0; s < NS; ++s) sums[s] = partial[s];
+      npairs = (long long)(partial[NS] + 0.5);
+    }
+  } else {
+    tree_stage2<NS, NACT>(partial, pcount, nblocks, sums, npairs);  // sums [NACT..NS) read as 0
+  }
   STEP_STAMP(i, 1);
   if (done) {
     if (threadIdx.x == 0) publish_progress(st);

@@ -274,6 +274,15 @@ int icpk_comm_gather_results(icpk_ctx *ctx, const float *T_local, const icpk_sta
  * ranks in place; one ncclAllReduce of (n + 1) doubles per iteration */
 int icpk_comm_allreduce_sums(icpk_ctx *ctx, double *sums, int32_t n, int64_t *count);
 int icpk_comm_barrier(icpk_ctx *ctx);
+/* Query-sharded alignment of ONE pair over the communicator's ranks (SURVEY.md 8e alternative; the frame-pair
+ * formulation icp.cpp:541-563 with the queries split): same target on every rank (icpk_comm_broadcast_target),
+ * source = this rank's slice of the queries; collective call.  The whole loop is enqueued: per iteration the grid
+ * sweep and the reduction on the slice, then ONE in-stream ncclAllReduce of 20 doubles (19 sums + pair count) and
+ * the replicated loop step on the reduced sums -- no host round trip per iteration.  reference and Kabsch
+ * flavours.  Every rank returns the same T and statistics (final_pairs = all ranks' pairs); they agree with
+ * icpk_align on the whole pair to ~1e-6 (the ranks' sums are added in the collective's order), bit for bit
+ * with one rank. */
+int icpk_align_query_sharded(icpk_ctx *ctx, const icpk_params *p, float T_out[16], icpk_stats *stats);
 
 /* ---- front end -------------------------------------- */
 /* pointcloud.cpp:19-58 without the rand()%40 subsample: row-major back-

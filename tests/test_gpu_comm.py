@@ -74,6 +74,21 @@ def test_world_of_one_round_trip(ctx):
         ctx.reset_source()
         T2, st2, _ = ctx.align(max_iterations=4, solve=binding.SOLVE_KABSCH, fixed_iterations=1, host_loop=1)
         assert status == 0 and it == 4 and n == st2.final_pairs and np.linalg.norm(T1.astype(np.float64) - T2) < 1e-6
+        # the device-side sharded loop with ONE rank (real RCCL, in-stream all-reduce): the reduced sums ARE the rank's
+        # canonical sums, so it must reproduce icpk_align bit for bit -- transform, statistics, associations, moved source
+        for kw in (dict(max_iterations=6, solve=binding.SOLVE_REFERENCE, fixed_iterations=1),
+                   dict(max_iterations=6, solve=binding.SOLVE_KABSCH, fixed_iterations=1),
+                   dict(max_iterations=16, solve=binding.SOLVE_KABSCH, threshold=1e-4)):
+            ctx.reset_source()
+            Ta, sta, rca = ctx.align(**kw)
+            ia, da = ctx.get_associations()
+            sa = ctx.get_source()
+            ctx.reset_source()
+            Tb2, stb, rcb = ctx.align_query_sharded(**kw)
+            ib, db = ctx.get_associations()
+            assert np.array_equal(Ta, Tb2) and (rca, sta.iterations, sta.final_pairs, sta.final_mse) == (rcb, stb.iterations, stb.final_pairs, stb.final_mse)
+            assert np.array_equal(ia, ib) and np.array_equal(da.view(np.uint32), db.view(np.uint32))
+            assert np.array_equal(sa.view(np.uint32), ctx.get_source().view(np.uint32))
     finally:
         comm.close()
     assert ctx.comm_world == 0

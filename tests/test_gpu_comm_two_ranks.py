@@ -75,6 +75,16 @@ def _worker(rank, world, fake, q_id, q_out):
     s0, c0 = batch.partition(big["source"].shape[1], world, rank)
     ctx.set_source(np.ascontiguousarray(big["source"][:, s0:s0 + c0]))
     res["sharded"] = batch.align_query_sharded(batch.ContextSteps(ctx), comm, max_iterations=5, solve=1, fixed_iterations=True)
+    # (6) the same through the DEVICE-side loop (icpk_align_query_sharded: in-stream all-reduce, no host round trip),
+    # both flavours, fixed iterations and threshold exit
+    res["sharded_dev"] = []
+    for kw in (dict(max_iterations=5, solve=1, fixed_iterations=1), dict(max_iterations=6, solve=0, fixed_iterations=1),
+               dict(max_iterations=12, solve=1, threshold=3e-4)):
+        res["sharded_dev"].append(comm.align_query_sharded(**kw))
+    ctx.reset_source()
+    ctx.transform_source(np.eye(3, dtype=np.float32), np.float32([50, 0, 0]))  # out of reach: the < 3 pairs fallback on every rank
+    ctx.commit_source()
+    res["sharded_dev_far"] = comm.align_query_sharded(max_iterations=4, solve=0, fixed_iterations=1, last_translation=np.float32([0.1, 0, 0]))
     comm.barrier()
     comm.close()
     ctx.close()
@@ -132,3 +142,23 @@ def test_two_ranks_on_one_gpu_through_the_c_abi(oracle):
     Ts, it, n, mse, status = got[0]["sharded"]
     assert it == 5 and status == 0 and n == st2.final_pairs
     assert np.linalg.norm(Ts.astype(np.float64) - T2.astype(np.float64)) < 1e-5
+    # (6) the device-side sharded loop: identical on both ranks, and equal to the single-context loop up to the order
+    # the halves' sums are added in -- same iterations, same exit, same pair count
+    ctx = binding.Context(0)
+    ctx.set_target(big["target"])
+    for k, kw in enumerate((dict(max_iterations=5, solve=1, fixed_iterations=1), dict(max_iterations=6, solve=0, fixed_iterations=1),
+                            dict(max_iterations=12, solve=1, threshold=3e-4))):
+        ctx.set_source(big["source"])
+        T3, st3, rc3 = ctx.align(**kw)
+        a, b = got[0]["sharded_dev"][k], got[1]["sharded_dev"][k]
+        assert np.array_equal(a[0], b[0]) and a[1:] == b[1:]
+        assert (a[1], a[2], a[4]) == (st3.iterations, st3.final_pairs, rc3), (k, a[1:], st3.iterations, st3.final_pairs)
+        assert np.linalg.norm(a[0].astype(np.float64) - T3.astype(np.float64)) < 1e-5
+    ctx.set_source(big["source"])
+    ctx.transform_source(np.eye(3, dtype=np.float32), np.float32([50, 0, 0]))
+    ctx.commit_source()
+    T4, st4, rc4 = ctx.align(max_iterations=4, solve=0, fixed_iterations=1, last_translation=np.float32([0.1, 0, 0]))
+    ctx.close()
+    a, b = got[0]["sharded_dev_far"], got[1]["sharded_dev_far"]
+    assert np.array_equal(a[0], b[0]) and a[4] == b[4] == rc4 == binding.W_TOO_FEW_PAIRS
+    assert np.array_equal(a[0], T4) and a[1] == st4.iterations
