@@ -4,7 +4,7 @@
 # copies go to profiles/<tag>_bench_kernel_stats.csv and <tag>_bench_under_rocprof.json.
 # A second pass profiles the N = 1 frame_batch block alone through tools/one_align.py --batch.
 cd /tmp && export TMPDIR=/tmp
-tag=${1:-r02}
+tag=${1:-r03}
 out=$GRAFT_REPO_ROOT/gpurun_out/profiles_new
 mkdir -p $out
 rm -rf /tmp/prof_bench
