@@ -73,7 +73,7 @@ struct icpk_ctx {
   int* progress = nullptr;       // pinned, mapped: LoopState::progress of a throttled loop (see there)
   int* progress_dev = nullptr;   // the same words as the device addresses them
   int loop_epoch = 0;            // tag of the current throttled loop in the progress words
-  int loop_ahead = 2;            // iterations kept enqueued ahead of the device in a loop that may exit early
+  int loop_ahead = 1;            // iterations kept enqueued ahead of the device in a loop that may exit early
   const int* stop = nullptr;     // &st_dev->done while a device loop is being enqueued, else null
   LoopState* st_active = nullptr;  // st_dev while a device loop is being enqueued, else null
   float* stage_t = nullptr;  // pinned staging of host clouds (frame-batch slots): target, source
@@ -134,6 +134,11 @@ struct icpk_ctx {
   int* qstart = nullptr;
   bool qcount_dirty = false; // a counting sort was cut short: clear the whole count table before the next one
   int* scan_bsum = nullptr;  // block sums of the cell-count scans (GRID_SCAN_BLOCKS ints)
+  // a fresh pair sorts targets and queries side by side (build_grid_and_order): second count table, block sums and slots
+  int* qcount2 = nullptr;
+  int* scan_bsum2 = nullptr;
+  int* sort_vals2 = nullptr;
+  int sort_vals2_cap = 0;
   int loop_nact = icpk::NSUM;      // device loop: sums the running alignment's step consumes (NSUM_REF or NSUM)
   int profile_phase = 0;     // alignments profiled so far (offsets the sampled launches, see profile_stride)
   int qperm_kind = 0;        // what qperm holds: 1 Morton order (pruned scan), 2 cell order (grid scan)
@@ -143,6 +148,7 @@ struct icpk_ctx {
   int grid_xdiv = 4;       // cells are this many times finer along x (ICPK_GRID_XDIV; measured best on config 2: 4)
   float grid_ppc = 8.f;    // aimed-at targets per occupied cell (ICPK_GRID_PPC; measured best on configs 2, 3 and the dense pair: 8)
   int grid_slices = 0;     // lanes per query (0 = by cloud size)
+  int merged_setup = 1;    // a fresh pair's two counting sorts side by side (ICPK_MERGED_SETUP=0: one after the other)
   std::string err;
   icpk_log_fn log_fn = nullptr;
   void* log_user = nullptr;

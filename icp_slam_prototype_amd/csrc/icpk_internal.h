@@ -403,5 +403,6 @@ void launch_grid_qslot_batch(const SetupBatchOf<QslotArgs>& b, int count, hipStr
 void launch_grid_scan_batch(const SetupBatchOf<ScanArgs>& b, int count, hipStream_t s);
 void launch_grid_tscatter_batch(const SetupBatchOf<TscatterArgs>& b, int count, hipStream_t s);
 void launch_grid_qscatter_batch(const SetupBatchOf<QscatterArgs>& b, int count, hipStream_t s);
+void launch_grid_tqscatter(const TscatterArgs& t, const QscatterArgs& q, hipStream_t s);
 
 }  // namespace icpk

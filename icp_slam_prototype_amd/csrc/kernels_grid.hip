@@ -361,6 +361,18 @@ void launch_grid_qscatter_batch(const SetupBatchOf<QscatterArgs>& b, int count, 
   if (count > 0 && m > 0) hipLaunchKernelGGL(grid_qscatter_batch_kernel, dim3((m + 255) / 256, count), dim3(256), 0, s, b);
 }
 
+// the two scatters of a fresh pair's set-up (targets into the cell-sorted copies, queries into scan order) in one launch
+__global__ void grid_tqscatter_kernel(const TscatterArgs t, const QscatterArgs q) {
+  if (blockIdx.y == 0)
+    grid_tscatter_body(t, blockIdx.x);
+  else
+    grid_qscatter_body(q, blockIdx.x);
+}
+void launch_grid_tqscatter(const TscatterArgs& t, const QscatterArgs& q, hipStream_t s) {
+  const int m = t.n > q.n ? t.n : q.n;
+  if (m > 0) hipLaunchKernelGGL(grid_tqscatter_kernel, dim3((m + 255) / 256, 2), dim3(256), 0, s, t, q);
+}
+
 int grid_bounds_parts(int n) {  // one 1024-thread block per 2048 points, at most GRID_BOUNDS_PARTS
   int nb = (n + 2047) / 2048;
   return nb < 1 ? 1 : (nb > GRID_BOUNDS_PARTS ? GRID_BOUNDS_PARTS : nb);
