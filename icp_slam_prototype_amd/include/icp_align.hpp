@@ -143,6 +143,14 @@ class Comm {
     icpk_comm_partition(n_items, world(), rank(), start, count);
   }
   int broadcastTarget(int root = 0) { return icpk_comm_broadcast_target(eng_.ctx(), root); }
+  // ONE large pair, queries sharded over the ranks (collective call): the engine's source is this rank's slice of
+  // the queries, the target the same on every rank (broadcastTarget); one in-stream all-reduce per iteration, no host
+  // round trip.  Every rank gets the same result.
+  int alignQuerySharded(const AlignParams& params, AlignResult* result) {
+    if (!result) return ICPK_E_ARG;
+    result->status = icpk_align_query_sharded(eng_.ctx(), &params, result->T, &result->stats);
+    return result->status;
+  }
   // local: this rank's block of results; all: resized to n_total, global pair order
   int gatherResults(const std::vector<AlignResult>& local, int32_t n_total, std::vector<AlignResult>* all) {
     if (!all) return ICPK_E_ARG;

@@ -100,6 +100,10 @@ int main(int argc, char** argv) {
         for (size_t k = 0; cagree && k < 3; ++k)
           cagree = std::memcmp(all[k].T, br[k].T, sizeof(r.T)) == 0 && all[k].stats.iterations == br[k].stats.iterations &&
                    all[k].stats.final_pairs == br[k].stats.final_pairs;
+        // the query-sharded device loop with one rank: the engine still holds the pair of icp::align(eng, ...) above
+        icp::AlignResult rs;
+        cagree = cagree && comm.alignQuerySharded(p, &rs) == rc && std::memcmp(rs.T, r.T, sizeof(r.T)) == 0 &&
+                 rs.stats.iterations == r.stats.iterations && rs.stats.final_pairs == r.stats.final_pairs;
       }
       std::fwrite(&cagree, 4, 1, o);
       std::vector<uint16_t> img = frames[0];
