@@ -962,9 +962,11 @@ def test_grid_non_finite_targets(ctx):
 
 
 @pytest.mark.parametrize("env", [{"ICPK_GRID_SLICES": "1"}, {"ICPK_GRID_SLICES": "2"}, {"ICPK_GRID_SLICES": "4"},
-                                 {"ICPK_GRID_PPC": "0.25"}, {"ICPK_GRID_PPC": "400"}])
+                                 {"ICPK_GRID_PPC": "0.25"}, {"ICPK_GRID_PPC": "400"}, {"ICPK_MERGED_SETUP": "0"},
+                                 {"ICPK_LOOP_AHEAD": "0"}, {"ICPK_LOOP_AHEAD": "3"}, {"ICPK_GRID_XDIV": "1"}])
 def test_grid_tuning_knobs_do_not_change_results(env, monkeypatch):
-    """Lanes per query and cell size are performance knobs only (read at context creation)."""
+    """Lanes per query, cell size, the side-by-side set-up of a fresh pair and the look-ahead of the throttled loop are
+    performance knobs only (read at context creation)."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     c = binding.Context(0)
@@ -980,5 +982,8 @@ def test_grid_tuning_knobs_do_not_change_results(env, monkeypatch):
         T1, s1, _ = c.align(max_iterations=4, fixed_iterations=1, nn_mode=binding.NN_GRID)
         T2, s2, _ = c.align(max_iterations=4, fixed_iterations=1, nn_mode=binding.NN_EXACT)
         assert np.array_equal(T1, T2) and s1.final_pairs == s2.final_pairs
+        T3, s3, r3 = c.align(max_iterations=14, threshold=2e-4, solve=binding.SOLVE_KABSCH, nn_mode=binding.NN_GRID)
+        T4, s4, r4 = c.align(max_iterations=14, threshold=2e-4, solve=binding.SOLVE_KABSCH, nn_mode=binding.NN_EXACT, host_loop=1)
+        assert np.array_equal(T3, T4) and (r3, s3.iterations, s3.final_pairs) == (r4, s4.iterations, s4.final_pairs)
     finally:
         c.close()
