@@ -29,6 +29,15 @@ inline Tracker& default_tracker() {
   return tracker;
 }
 
+// SLAM.cpp:305 hands every frame back as the next call's `previous` (previous = filtered.clone()).  With this switch
+// on, calls after the first take `previous` from the device, where the last call's `data` has stayed, instead of
+// uploading it again (icp::Tracker::getTransformation(data, nullptr, ...): same results).  Leave it off if the caller
+// may hand over a `previous` that is NOT the last call's `data`.
+inline bool& sequential_frames() {
+  static bool on = false;
+  return on;
+}
+
 inline cv::Mat getTransformation(cv::Mat& data, cv::Mat& previous, cv::Mat /*color*/,
                                  std::vector<cv::KeyPoint> /*keypoints*/, cv::Mat& /*rotation*/, int maxIterations,
                                  float threshold, cv::viz::Viz3d& /*depthWindow*/) {
@@ -37,7 +46,16 @@ inline cv::Mat getTransformation(cv::Mat& data, cv::Mat& previous, cv::Mat /*col
   cv::Mat p = previous.isContinuous() ? previous : previous.clone();
   cv::Mat rigidTransformation(4, 4, CV_32FC1);
   float T[16];
-  default_tracker().getTransformation(d.ptr<uint16_t>(), p.ptr<uint16_t>(), d.rows, d.cols, maxIterations, threshold, T);
+  static bool have_previous = false;  // a frame of this size is resident from the last call
+  static int last_rows = 0, last_cols = 0;
+  const bool resident = sequential_frames() && have_previous && last_rows == d.rows && last_cols == d.cols;
+  int rc = default_tracker().getTransformation(d.ptr<uint16_t>(), resident ? nullptr : p.ptr<uint16_t>(), d.rows, d.cols,
+                                               maxIterations, threshold, T);
+  if (rc == ICPK_E_NOT_SET && resident)  // (the image buffers were used by another call in between: upload both)
+    rc = default_tracker().getTransformation(d.ptr<uint16_t>(), p.ptr<uint16_t>(), d.rows, d.cols, maxIterations, threshold, T);
+  have_previous = rc >= 0;
+  last_rows = d.rows;
+  last_cols = d.cols;
   std::memcpy(rigidTransformation.ptr<float>(), T, sizeof(T));
   return rigidTransformation;
 }
