@@ -669,7 +669,10 @@ __device__ __forceinline__ void nn_grid_body(
         }
         float4 v[GB];
 #pragma unroll
-        for (int k = 0; k < GB; ++k) v[k] = t4[v0 + k * S < C ? pk[k] : 0];
+        for (int k = 0; k < GB; ++k) {
+          v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (v0 + k * S < C) v[k] = t4[pk[k]];  // (lanes without a candidate issue no load)
+        }
 #if defined(ICPK_GRID_STAMPS) && !defined(ICPK_GRID_COUNTS)
         if (v[GB - 1].x == v[GB - 1].x && r0 == 0 && grid_dbg[wave_id * 8 + 6] == 0) GRID_STAMP(6);  // first batch has arrived
 #endif
