@@ -353,8 +353,12 @@ int build_grid_and_order(icpk_ctx* ctx) {
   const size_t table = ((size_t)ctx->grid_max_cells + 1) * sizeof(int);
   if (!ctx->qcount2) {
     ICPK_HIP(ctx, hipMalloc((void**)&ctx->qcount2, table));
-    ICPK_HIP(ctx, hipMemsetAsync(ctx->qcount2, 0, table, ctx->stream));  // (handed back zeroed by every scan from here on)
     ICPK_HIP(ctx, hipMalloc((void**)&ctx->scan_bsum2, (size_t)GRID_SCAN_BLOCKS * sizeof(int)));
+    ctx->qcount2_dirty = true;
+  }
+  if (ctx->qcount2_dirty) {  // (first use, or a sort that was cut short: the scans hand the table back zeroed otherwise)
+    ICPK_HIP(ctx, hipMemsetAsync(ctx->qcount2, 0, table, ctx->stream));
+    ctx->qcount2_dirty = false;
   }
   if (ctx->sort_cap > ctx->sort_vals2_cap) {
     if (ctx->sort_vals2) ICPK_HIP(ctx, hipFree(ctx->sort_vals2));
@@ -369,7 +373,7 @@ int build_grid_and_order(icpk_ctx* ctx) {
   int* qslot = ctx->sort_vals2;
   launch_grid_bounds(ctx->tgt.x(), ctx->tgt.y(), ctx->tgt.z(), nt, ctx->grid_bounds, ctx->stream);
   launch_grid_info(ctx->grid_bounds, nt, ctx->grid_ppc, ctx->grid_xdiv, ctx->grid_max_cells, ctx->grid_info, ctx->stream);
-  ctx->qcount_dirty = true;
+  ctx->qcount_dirty = ctx->qcount2_dirty = true;
   SetupBatchOf<QslotArgs> qb{};
   qb.p[0] = QslotArgs{ctx->tgt.x(), ctx->tgt.y(), ctx->tgt.z(), ctx->grid_info, ctx->qcount, tcell, tslot, nt, 0};
   qb.p[1] = QslotArgs{ctx->src.x(), ctx->src.y(), ctx->src.z(), ctx->grid_info, ctx->qcount2, qcell, qslot, nq, 1};
@@ -383,7 +387,7 @@ int build_grid_and_order(icpk_ctx* ctx) {
                         ctx->tgt.y(), ctx->tgt.z(), ctx->qm4,     ctx->sp_in,   ctx->seed_m,  nq,           0};
   launch_grid_tqscatter(ta, qa, ctx->stream);
   ICPK_HIP(ctx, hipGetLastError());
-  ctx->qcount_dirty = false;
+  ctx->qcount_dirty = ctx->qcount2_dirty = false;
   ctx->have_grid = true;
   return ICPK_OK;
 }

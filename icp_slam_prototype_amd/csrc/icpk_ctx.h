@@ -136,6 +136,7 @@ struct icpk_ctx {
   int* scan_bsum = nullptr;  // block sums of the cell-count scans (GRID_SCAN_BLOCKS ints)
   // a fresh pair sorts targets and queries side by side (build_grid_and_order): second count table, block sums and slots
   int* qcount2 = nullptr;
+  bool qcount2_dirty = false;
   int* scan_bsum2 = nullptr;
   int* sort_vals2 = nullptr;
   int sort_vals2_cap = 0;
