@@ -263,6 +263,7 @@ int ensure_scan_buffers(icpk_ctx* ctx) {
 // next group's grids in the shadow of the running loop.
 int prepare_grid_target(icpk_ctx* ctx) {
   const int nt = ctx->tgt.n;
+  if (nt > (1 << 28)) return fail(ctx, ICPK_E_ARG, "the grid search addresses its cell-sorted targets with 32-bit byte offsets: at most 2^28 target points");
   if (!ctx->grid_info) ICPK_HIP(ctx, hipMalloc((void**)&ctx->grid_info, sizeof(GridInfo)));
   if (!ctx->grid_bounds)
     ICPK_HIP(ctx, hipMalloc((void**)&ctx->grid_bounds, (size_t)GRID_BOUNDS_PARTS * 6 * sizeof(float)));
@@ -333,6 +334,7 @@ int ensure_query_points(icpk_ctx* ctx, int nq);
 // path that is a chain of tiny dependent kernels.
 int build_grid_and_order(icpk_ctx* ctx) {
   const int nt = ctx->tgt.n, nq = ctx->src.n;
+  if (nt > (1 << 28)) return fail(ctx, ICPK_E_ARG, "the grid search addresses its cell-sorted targets with 32-bit byte offsets: at most 2^28 target points");
   if (!ctx->grid_info) ICPK_HIP(ctx, hipMalloc((void**)&ctx->grid_info, sizeof(GridInfo)));
   if (!ctx->grid_bounds)
     ICPK_HIP(ctx, hipMalloc((void**)&ctx->grid_bounds, (size_t)GRID_BOUNDS_PARTS * 6 * sizeof(float)));
@@ -507,7 +509,7 @@ int prepare_sorted_sweep(icpk_ctx* ctx, int nn_mode, NnArgs& a, NnBoxes& bx, int
 
 // lanes per query of the grid scan (measured with cells 4x finer along x: 8 is best up to 217k queries, 4 from
 // 307k on; a launch that fills the GPU several times over is issue-bound and prefers fewer, longer lanes)
-int grid_slices_for(const icpk_ctx* ctx, int nq) { return ctx->grid_slices ? ctx->grid_slices : (nq > 262144 ? 4 : 8); }
+int grid_slices_for(const icpk_ctx* ctx, int nq) { return ctx->grid_slices ? ctx->grid_slices : (nq > 524288 ? 4 : 8); }
 
 // the K1d arguments of the sweep prepare_sorted_sweep has just set up, and the bookkeeping
 // that follows its launch

@@ -497,6 +497,12 @@ constexpr bool GRID_BALL_TRIM = true;
 // point, index)}, two adjacent 16-byte stores, which is all K2 reads; the caller's planes and keys (three 4-byte and one
 // 8-byte scattered store per query and sweep, each paying for a whole sector) are written ONCE after the loop by
 // grid_unpack_kernel.  Same values either way.
+__device__ __forceinline__ int bcnt_acc(unsigned x, int acc) {  // popcount(x) + acc in one instruction
+  int r;
+  asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
+  return r;
+}
+
 template <int S, bool EXPAND, bool REC>
 __device__ __forceinline__ void nn_grid_body(
     float* __restrict__ qxp, float* __restrict__ qyp, float* __restrict__ qzp, const int nq, float4* __restrict__ qm4,
@@ -573,7 +579,7 @@ __device__ __forceinline__ void nn_grid_body(
 #define ICPK_GRID_GB 5  // (with cells 4x finer along x a query has ~32 candidates: 5 per lane and trip, 70 VGPRs -> 7 waves/SIMD)
 #endif
   constexpr int GB = ICPK_GRID_GB;
-  __shared__ int2 rowtab[64];  // per query and row of the chunk: (inclusive prefix, start - exclusive prefix)
+  __shared__ int2 rowtab[64 + 8];  // (+ padding, see the byte count below) per query and row of the chunk: (inclusive prefix, start - exclusive prefix)
   int2* const tab = &rowtab[lane & ~(S - 1)];
   auto scan_cells = [&](int x0, int x1, int y0, int y1, int z0, int z1) {
     const int nyr = y1 - y0 + 1;
@@ -652,26 +658,55 @@ __device__ __forceinline__ void nn_grid_body(
       __builtin_amdgcn_wave_barrier();  // the previous chunk's table has been read
       tab[slice] = make_int2(P, s0 - (P - len));
       __builtin_amdgcn_wave_barrier();  // (one wave per workgroup: LDS operations complete in order)
+      // Which row candidate number v lies in = how many of the S inclusive prefixes are <= v.  While every chunk of
+      // the wave has at most 127 candidates (the steady state: ~30) the prefixes fit a byte each, all S of them sit
+      // in one or two registers (their order does not matter for a count), and ((v | 0x80) - P) has its top bit set
+      // exactly in the bytes with P <= v: two subtractions, two ANDs and two population counts per candidate instead
+      // of a chain of S compare-and-select pairs.  Same row, same address.
+      unsigned W0 = 0, W1 = 0;
+      bool small = false;
+      if constexpr (S == 4 || S == 8) {
+        small = __builtin_amdgcn_ballot_w64(C > 127) == 0;
+        if (small) {
+          W0 = (unsigned)P;
+          W0 |= (unsigned)dpp_mov<0xB1>((int)W0) << 8;   // quad_perm [1,0,3,2]
+          W0 |= (unsigned)dpp_mov<0x4E>((int)W0) << 16;  // quad_perm [2,3,0,1]: the quad's four prefixes
+          if constexpr (S == 8) W1 = (unsigned)dpp_mov<0x141>((int)W0);  // row_half_mirror: the other quad's
+        }
+      }
 #if defined(ICPK_GRID_STAMPS) && !defined(ICPK_GRID_COUNTS)
       if (C > -1 && r0 == 0 && grid_dbg[wave_id * 8 + 5] == 0) GRID_STAMP(5);  // ranges have arrived
 #endif
       for (int v0 = slice; v0 < C; v0 += S * GB) {
         int pk[GB];
-        int2 rt = tab[0];
+        if (small) {
+          unsigned vr = (unsigned)v0 * 0x01010101u + 0x80808080u;
 #pragma unroll
-        for (int k = 0; k < GB; ++k) pk[k] = rt.y + v0 + k * S;
+          for (int k = 0; k < GB; ++k) {
+            int r = bcnt_acc((vr - W0) & 0x80808080u, 0);
+            if constexpr (S == 8) r = bcnt_acc((vr - W1) & 0x80808080u, r);
+            pk[k] = tab[r].y + v0 + k * S;  // (r == S only for v >= C: a lane without a candidate; the entry read is padding)
+            vr += (unsigned)S * 0x01010101u;
+          }
+        } else {
+          int2 rt = tab[0];
 #pragma unroll
-        for (int t = 1; t < S; ++t) {
-          const int pprev = rt.x;
-          rt = tab[t];
+          for (int k = 0; k < GB; ++k) pk[k] = rt.y + v0 + k * S;
 #pragma unroll
-          for (int k = 0; k < GB; ++k) pk[k] = v0 + k * S >= pprev ? rt.y + v0 + k * S : pk[k];
+          for (int t = 1; t < S; ++t) {
+            const int pprev = rt.x;
+            rt = tab[t];
+#pragma unroll
+            for (int k = 0; k < GB; ++k) pk[k] = v0 + k * S >= pprev ? rt.y + v0 + k * S : pk[k];
+          }
         }
         float4 v[GB];
 #pragma unroll
         for (int k = 0; k < GB; ++k) {
-          v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (v0 + k * S < C) v[k] = t4[pk[k]];  // (lanes without a candidate issue no load)
+          // (lanes without a candidate issue no load; what their registers hold is never looked at -- the test below
+          // repeats v < C -- so they are left as they are instead of being cleared: four moves per candidate)
+          asm volatile("" : "=v"(v[k].x), "=v"(v[k].y), "=v"(v[k].z), "=v"(v[k].w));
+          if (v0 + k * S < C) v[k] = *(const float4*)((const char*)t4 + ((unsigned)pk[k] << 4));  // (< 2^28 targets: icpk_set_target)
         }
 #if defined(ICPK_GRID_STAMPS) && !defined(ICPK_GRID_COUNTS)
         if (v[GB - 1].x == v[GB - 1].x && r0 == 0 && grid_dbg[wave_id * 8 + 6] == 0) GRID_STAMP(6);  // first batch has arrived

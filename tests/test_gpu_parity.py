@@ -961,6 +961,32 @@ def test_grid_non_finite_targets(ctx):
     assert not np.isin(ie, [17, 900, 5999]).any() and np.isfinite(de).all()
 
 
+@pytest.mark.parametrize("slices", ["8", "4"])
+def test_grid_row_lookup_on_both_sides_of_127_candidates(slices, monkeypatch):
+    """A chunk of rows with at most 127 candidates finds each candidate's row by a byte-wise count of the row
+    prefixes, a larger one by the compare chain (kernels_grid.hip, nn_grid_body): a blob of 60 ... 140 and of
+    250 ... 260 targets inside one cell walks the chunk size across both limits, for 8 and for 4 lanes per query."""
+    monkeypatch.setenv("ICPK_GRID_SLICES", slices)
+    c = binding.Context(0)
+    try:
+        rng = np.random.default_rng(127)
+        back = rng.uniform(0, 1, (3, 8000)).astype(np.float32)
+        centre = np.array([[0.5125], [0.51], [0.51]], np.float32)
+        src = (centre + rng.normal(0, 0.04, (3, 600))).astype(np.float32)
+        for blob in list(range(60, 141, 2)) + [250, 254, 255, 256, 260]:
+            tgt = np.concatenate([back, (centre + rng.uniform(-0.002, 0.002, (3, blob))).astype(np.float32)], 1)
+            _grid_vs_exact(c, src, tgt, sweeps=1)
+            # seeded sweeps from STALE seeds (the matches of the sweep before the motion): the one-pass search whose
+            # chunks hold the whole cube of the seed distance
+            for t in ([0.013, -0.007, 0.004], [-0.02, 0.01, 0.015]):
+                c.transform_source(np.eye(3, dtype=np.float32), np.float32(t))
+                ig, dg = c.nn(binding.NN_GRID)
+                ie, de = c.nn(binding.NN_EXACT)
+                assert np.array_equal(ie, ig) and np.array_equal(de.view(np.uint32), dg.view(np.uint32)), (blob, t)
+    finally:
+        c.close()
+
+
 @pytest.mark.parametrize("env", [{"ICPK_GRID_SLICES": "1"}, {"ICPK_GRID_SLICES": "2"}, {"ICPK_GRID_SLICES": "4"},
                                  {"ICPK_GRID_PPC": "0.25"}, {"ICPK_GRID_PPC": "400"}, {"ICPK_MERGED_SETUP": "0"},
                                  {"ICPK_LOOP_AHEAD": "0"}, {"ICPK_LOOP_AHEAD": "3"}, {"ICPK_GRID_XDIV": "1"}])
