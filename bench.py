@@ -583,6 +583,22 @@ def extra_point_to_plane(args, torch, dev, gpu_index, iters=20, steps=10):
             "nn_mpoints_per_s": nn_launches * nq / elapsed / 1e6, "nn_kernel_avg_launch_ms": nn_ms / max(nn_timed, 1)}
 
 
+def tracker_frames():
+    from icp_slam_prototype_amd import synth
+
+    rng = np.random.default_rng(0)
+    frames = []
+    for k in range(6):
+        d = synth.render_room_depth(480, 640, synth.rot_xyz_deg(0, 0.5 * k, 0), np.array([0.01 * k, 0, 0]),
+                                    noise_sigma=0.002, rng=rng)
+        d[rng.random(d.shape) > 0.3] = 0
+        frames.append(d.astype(np.uint16))
+    return frames
+
+
+_NATIVE_TRACKER = None  # tracker_path_native's result when main() ran it before this process touched the GPU
+
+
 def tracker_path(gpu_index):
     """The callers either side of the loop as SLAM.cpp drives them --
     icp::Tracker::getTransformation's call sequence through the C ABI (icpk_backproject_pair,
@@ -592,13 +608,7 @@ def tracker_path(gpu_index):
     nature; frame pairs per second."""
     from icp_slam_prototype_amd import binding, synth
 
-    rng = np.random.default_rng(0)
-    frames = []
-    for k in range(6):
-        d = synth.render_room_depth(480, 640, synth.rot_xyz_deg(0, 0.5 * k, 0), np.array([0.01 * k, 0, 0]),
-                                    noise_sigma=0.002, rng=rng)
-        d[rng.random(d.shape) > 0.3] = 0
-        frames.append(d.astype(np.uint16))
+    frames = tracker_frames()
     ctx = binding.Context(gpu_index)
     camR, camP = np.eye(3, dtype=np.float32), np.full(3, 5, np.float32)
     res = {}
@@ -636,10 +646,43 @@ def tracker_path(gpu_index):
                     "points": [ctx.source_size, ctx.target_size],
                     "host_ms_per_call": {k: round(v / n * 1e3, 4) for k, v in stage.items()}}
     ctx.close()
+    # the same call sequence from a C++ caller (what a drop-in user of icp.cpp is): tests/cpp/tracker_bench.cpp as a
+    # child process on the same frames -- no interpreter between the calls
+    # (run by main() BEFORE this process initialised the GPU: with a second process holding queues on the card the
+    # child's 614 KB uploads take ~260 us instead of ~70 -- an artefact of two processes on one GPU, not of either path)
+    if _NATIVE_TRACKER is not None:
+        res["native_cpp"] = _NATIVE_TRACKER
+    else:
+        try:
+            res["native_cpp"] = dict(tracker_path_native(frames, gpu_index, rounds=8), beside_the_bench_process=True)
+        except Exception as e:  # (the Python-driven figures above stand on their own)
+            res["native_cpp"] = {"error": repr(e)[:300]}
     res["workload"] = ("6 synthetic 640x480 frames (30 % valid, camera drifting 0.5 degree / 1 cm per frame), consecutive pairs, "
                        "threshold exit; host depth images in, 4x4 + trace out; plain / with_filterDepthImage: the previous frame "
-                       "stays on the device (one upload per call); both_frames_uploaded: as round 2 measured it")
+                       "stays on the device (one upload per call); both_frames_uploaded: as round 2 measured it; these three "
+                       "through Python / ctypes (host_ms_per_call includes ~15 us of interpreter per call), native_cpp: the "
+                       "same C-ABI calls from tests/cpp/tracker_bench.cpp")
     return res
+
+
+def tracker_path_native(frames, gpu_index, rounds=8, filt=False, resident=True):
+    """tests/cpp/tracker_bench.cpp (prebuilt by __graft_entry__.build(); rebuilt here with g++ if missing) on `frames`."""
+    import subprocess
+    import tempfile
+
+    from icp_slam_prototype_amd import build as b
+
+    exe = b.TRACKER_BENCH if os.path.exists(b.TRACKER_BENCH) else b.build_tracker_bench()
+    rows, cols = frames[0].shape
+    with tempfile.NamedTemporaryFile(suffix=".u16") as f:
+        for d in frames:
+            f.write(np.ascontiguousarray(d, np.uint16).tobytes())
+        f.flush()
+        out = subprocess.run([exe, f.name, str(rows), str(cols), str(len(frames)), str(rounds), str(int(filt)),
+                              str(int(resident)), str(gpu_index)], capture_output=True, text=True, timeout=300)
+    if out.returncode != 0:
+        raise RuntimeError(f"tracker_bench rc {out.returncode}: {out.stderr[-300:]}")
+    return json.loads(out.stdout.strip().splitlines()[-1])
 
 
 # --------------------------------------------------------------------------------- N > 1 --
@@ -900,6 +943,14 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: N > 1 must be launched with one process per GPU "
                          f"(python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} ... bench.py --gpus {args.gpus})")
+
+    if world == 1 and not args.no_extras and args.workload == "kinect640x480_30pct" and args.solve == "reference" and args.nn_mode == "grid":
+        # the frame path from a C++ caller, measured while nothing else holds the GPU (see tracker_path)
+        global _NATIVE_TRACKER
+        try:
+            _NATIVE_TRACKER = dict(tracker_path_native(tracker_frames(), local_rank, rounds=8), beside_the_bench_process=False)
+        except Exception as e:
+            _NATIVE_TRACKER = {"error": repr(e)[:300]}
 
     import torch  # before the binding: libicpk.so must bind to the HIP runtime torch ships
 

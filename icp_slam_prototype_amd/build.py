@@ -63,6 +63,22 @@ def build_cpp_test(force=False):
     return CPP_TEST
 
 
+TRACKER_BENCH = os.path.join(LIBDIR, "tracker_bench")
+
+
+def build_tracker_bench(force=False):
+    """Host-only C++ program over the C ABI: the frame path timed without an interpreter (bench.py's tracker_path runs
+    it as a child process)."""
+    src = os.path.join(ROOT, "tests", "cpp", "tracker_bench.cpp")
+    build()
+    newest = max(os.path.getmtime(p) for p in (src, LIB, os.path.join(ROOT, "include", "icpk.h")))
+    if not force and os.path.exists(TRACKER_BENCH) and os.path.getmtime(TRACKER_BENCH) >= newest:
+        return TRACKER_BENCH
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-I", os.path.join(ROOT, "include"), src, "-L", LIBDIR,
+                           "-licpk", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath-link,/opt/rocm/lib", "-o", TRACKER_BENCH])
+    return TRACKER_BENCH
+
+
 FAKE_RCCL = os.path.join(LIBDIR, "libfake_rccl.so")
 
 
@@ -82,3 +98,4 @@ def build_fake_rccl(force=False):
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
     print(build_cpp_test(force="--force" in sys.argv))
+    print(build_tracker_bench(force="--force" in sys.argv))

@@ -31,6 +31,7 @@ int fail(icpk_ctx* ctx, int code, const char* msg) {
 }
 
 int ensure_cloud(icpk_ctx* ctx, Cloud& c, int n) {
+  if (ctx && (&c == &ctx->src0 || &c == &ctx->src)) ctx->src_pristine = false;  // (about to be resized or rewritten)
   const int cap = round_up(n < 1 ? 1 : n, NN_TILE);
   if (cap > c.cap) {
     if (c.base) ICPK_HIP(ctx, hipFree(c.base));
@@ -111,6 +112,9 @@ int upload_cloud(icpk_ctx* ctx, Cloud& c, const float* x, const float* y, const 
 }
 
 int copy_src0_to_src(icpk_ctx* ctx) {
+  // src_pristine: the working copy is known to hold the committed source already (icpk_backproject_pair writes both
+  // at once; nothing has touched either since) -- the frame path's icpk_align starts without this copy
+  if (ctx->src_pristine && ctx->pristine_skip && ctx->src.n == ctx->src0.n) return ICPK_OK;
   int rc = ensure_cloud(ctx, ctx->src, ctx->src0.n);
   if (rc) return rc;
   const Cloud &a = ctx->src0, &b = ctx->src;
@@ -122,6 +126,7 @@ int copy_src0_to_src(icpk_ctx* ctx) {
     ICPK_HIP(ctx, hipMemcpyAsync(b.y(), a.y(), (size_t)m * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
     ICPK_HIP(ctx, hipMemcpyAsync(b.z(), a.z(), (size_t)m * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
   }
+  ctx->src_pristine = true;
   return ICPK_OK;
 }
 
@@ -893,6 +898,7 @@ int icpk_create(icpk_ctx** out, int device_id) {
     if (v >= 1 && v <= 16) ctx->batch_threads = v;
   }
   if (const char* e = std::getenv("ICPK_BATCH_SETUP")) ctx->batch_setup = std::atoi(e);  // 0: per-pair launches; 2: batched launches for single-group host-pointer batches too; 3: as 2, replayed pair by pair
+  if (const char* e = std::getenv("ICPK_PRISTINE_SKIP")) ctx->pristine_skip = std::atoi(e) != 0;
   if (const char* e = std::getenv("ICPK_LOOP_AHEAD")) {  // 0: enqueue every iteration up front
     const int v = std::atoi(e);
     if (v >= 0 && v <= LOOP_MAX_ITER) ctx->loop_ahead = v;
@@ -1008,6 +1014,7 @@ int icpk_commit_source(icpk_ctx* ctx) {
   ICPK_HIP(ctx, hipMemcpyAsync(b.x(), a.x(), (size_t)m * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
   ICPK_HIP(ctx, hipMemcpyAsync(b.y(), a.y(), (size_t)m * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
   ICPK_HIP(ctx, hipMemcpyAsync(b.z(), a.z(), (size_t)m * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+  ctx->src_pristine = a.n == b.n;  // (the two copies are equal again)
   return ICPK_OK;  // stream-ordered: no host wait
 }
 
@@ -1100,6 +1107,7 @@ int icpk_transform_source(icpk_ctx* ctx, const float R[9], const float t[3]) {
   Rt rt;
   std::memcpy(rt.R, R, sizeof(rt.R));
   std::memcpy(rt.t, t, sizeof(rt.t));
+  ctx->src_pristine = false;
   launch_transform(ctx->src.x(), ctx->src.y(), ctx->src.z(), ctx->src.n, rt, ctx->stream);
   ICPK_HIP(ctx, hipGetLastError());
   ctx->have_assoc = false;
@@ -1358,6 +1366,7 @@ int icpk_align_query_sharded(icpk_ctx* ctx, const icpk_params* p, float T_out[16
   icpk_params q = *p;
   q.nn_mode = ICPK_NN_GRID;
   rc = copy_src0_to_src(ctx);  // like icpk_align: the alignment starts from the source as set / committed
+  ctx->src_pristine = false;   // (the loop moves the working copy)
   if (rc) return rc;
   ctx->have_seed = false;
   ctx->have_qperm = false;
@@ -1456,6 +1465,7 @@ int icpk_align(icpk_ctx* ctx, const icpk_params* p, float T_out[16], icpk_stats*
   ICPK_HIP(ctx, hipSetDevice(ctx->device));
   rc = copy_src0_to_src(ctx);
   if (rc) return rc;
+  ctx->src_pristine = false;  // (the loop moves the working copy)
   ctx->have_seed = false;  // matches of an earlier alignment belong to a different source pose
   ctx->have_qperm = false;
   ctx->trace_R.clear();
@@ -2290,6 +2300,7 @@ int icpk_backproject_pair(icpk_ctx* ctx, const uint16_t* depth_source, const uin
   ICPK_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the one host wait: both counts (and both images consumed)
   ctx->src0.n = ctx->src.n = ctx->bp_n_host[0];
   ctx->tgt.n = ctx->bp_n_host[1];
+  ctx->src_pristine = true;  // (the scatter wrote the committed and the working copy of the source at once)
   ctx->have_src = ctx->have_tgt = true;
   ctx->have_assoc = ctx->have_seed = ctx->have_qperm = false;
   ctx->have_dec = ctx->have_boxes = ctx->have_grid = ctx->have_normals = false;

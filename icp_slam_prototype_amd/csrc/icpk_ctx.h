@@ -73,6 +73,8 @@ struct icpk_ctx {
   int* progress = nullptr;       // pinned, mapped: LoopState::progress of a throttled loop (see there)
   int* progress_dev = nullptr;   // the same words as the device addresses them
   int loop_epoch = 0;            // tag of the current throttled loop in the progress words
+  bool src_pristine = false;     // the working source equals the committed one (see copy_src0_to_src)
+  bool pristine_skip = true;     // ICPK_PRISTINE_SKIP=0: always copy (diagnostic)
   int loop_ahead = 1;            // iterations kept enqueued ahead of the device in a loop that may exit early
   const int* stop = nullptr;     // &st_dev->done while a device loop is being enqueued, else null
   LoopState* st_active = nullptr;  // st_dev while a device loop is being enqueued, else null

@@ -27,19 +27,24 @@ namespace icpk {
 // distance is inf/NaN, and the seed of such a query is element 0, the lowest index)
 __device__ __forceinline__ void grid_bounds_body(const BoundsArgs& a, const int part) {
   __shared__ float red[6][16];
-  const float* p[3] = {a.x, a.y, a.z};
   float lo[3], hi[3];
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     lo[c] = __builtin_inff();
     hi[c] = -__builtin_inff();
-    for (int i = part * 1024 + threadIdx.x; i < a.n; i += a.nparts * 1024) {
-      const float v = p[c][i];
-      if (v - v == 0.f) {
-        lo[c] = __builtin_fminf(lo[c], v);
-        hi[c] = __builtin_fmaxf(hi[c], v);
+  }
+  // (the three planes in one loop: their loads are in flight together -- one memory phase, not three)
+  for (int i = part * 1024 + threadIdx.x; i < a.n; i += a.nparts * 1024) {
+    const float v[3] = {a.x[i], a.y[i], a.z[i]};
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      if (v[c] - v[c] == 0.f) {
+        lo[c] = __builtin_fminf(lo[c], v[c]);
+        hi[c] = __builtin_fmaxf(hi[c], v[c]);
       }
-    }
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) {
       lo[c] = __builtin_fminf(lo[c], __shfl_xor(lo[c], m, 64));
@@ -193,6 +198,7 @@ __global__ void grid_qscatter_batch_kernel(const SetupBatchOf<QscatterArgs> b) {
 // (hipMemset at allocation), so no sort starts with a zero-fill launch.
 constexpr int GSCAN_ITEMS = 8;
 constexpr int GSCAN_TILE = 256 * GSCAN_ITEMS;
+static_assert(GSCAN_ITEMS == 8, "grid_scan_apply_body unpacks two int4");
 // (the largest table, 2^23 + 1 entries, has 4097 tiles)
 
 __device__ __forceinline__ int grid_table_size(const GridInfo* __restrict__ gi, int coarse) {
@@ -248,11 +254,20 @@ __device__ __forceinline__ void grid_scan_apply_body(const ScanArgs& a, const in
     const int boff = block_sum_256(before, sh);
     // lane t owns the 8 consecutive counts base + 8 t .. base + 8 t + 7
     int c[GSCAN_ITEMS], s = 0;
+    const bool whole = base + GSCAN_TILE <= n;  // (all tiles but the last: 16-byte loads and stores, the tables are 16-byte aligned)
+    if (whole) {
+      const int4 lo4 = *reinterpret_cast<const int4*>(in + base + GSCAN_ITEMS * t);
+      const int4 hi4 = *reinterpret_cast<const int4*>(in + base + GSCAN_ITEMS * t + 4);
+      c[0] = lo4.x, c[1] = lo4.y, c[2] = lo4.z, c[3] = lo4.w, c[4] = hi4.x, c[5] = hi4.y, c[6] = hi4.z, c[7] = hi4.w;
 #pragma unroll
-    for (int k = 0; k < GSCAN_ITEMS; ++k) {
-      const int i = base + GSCAN_ITEMS * t + k;
-      c[k] = i < n ? in[i] : 0;
-      s += c[k];
+      for (int k = 0; k < GSCAN_ITEMS; ++k) s += c[k];
+    } else {
+#pragma unroll
+      for (int k = 0; k < GSCAN_ITEMS; ++k) {
+        const int i = base + GSCAN_ITEMS * t + k;
+        c[k] = i < n ? in[i] : 0;
+        s += c[k];
+      }
     }
     int inc = s;
 #pragma unroll
@@ -265,14 +280,28 @@ __device__ __forceinline__ void grid_scan_apply_body(const ScanArgs& a, const in
     __syncthreads();
     int run = boff + inc - s;
     for (int w = 0; w < wave; ++w) run += wtot[w];
+    if (whole) {
+      int o[GSCAN_ITEMS];
 #pragma unroll
-    for (int k = 0; k < GSCAN_ITEMS; ++k) {
-      const int i = base + GSCAN_ITEMS * t + k;
-      if (i < n) {
-        a.out[i] = run;
-        in[i] = 0;  // the table is handed back all zero
+      for (int k = 0; k < GSCAN_ITEMS; ++k) {
+        o[k] = run;
+        run += c[k];
       }
-      run += c[k];
+      int* const op = a.out + base + GSCAN_ITEMS * t;
+      *reinterpret_cast<int4*>(op) = make_int4(o[0], o[1], o[2], o[3]);
+      *reinterpret_cast<int4*>(op + 4) = make_int4(o[4], o[5], o[6], o[7]);
+      *reinterpret_cast<int4*>(in + base + GSCAN_ITEMS * t) = make_int4(0, 0, 0, 0);  // the table is handed back all zero
+      *reinterpret_cast<int4*>(in + base + GSCAN_ITEMS * t + 4) = make_int4(0, 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int k = 0; k < GSCAN_ITEMS; ++k) {
+        const int i = base + GSCAN_ITEMS * t + k;
+        if (i < n) {
+          a.out[i] = run;
+          in[i] = 0;
+        }
+        run += c[k];
+      }
     }
   }
 }

@@ -254,6 +254,59 @@ def test_backproject_pair_with_the_resident_previous_frame(filt):
         assert a.get_target().tobytes() == b.get_target().tobytes()
 
 
+def test_align_after_backproject_pair_skips_the_source_copy_only_when_it_may(monkeypatch):
+    """icpk_backproject_pair writes the committed and the working source at once, so the icpk_align that follows starts
+    without the device copy between them (ICPK_PRISTINE_SKIP=1, the default).  Every call that touches either copy in
+    between must bring the copy back: same transforms, iterations and aligned sources as a context that always copies,
+    over sequences that mix the pair call with transform / commit / reset / set_source / a second alignment."""
+    rows, cols = 96, 128
+    fx, cx = float(synth.FX) * cols / 640, float(synth.CX) * cols / 640
+    rng = np.random.default_rng(11)
+    frames = []
+    for k in range(4):
+        d = synth.render_room_depth(rows, cols, synth.rot_xyz_deg(0, 0.6 * k, 0), np.array([0.01 * k, 0, 0]), fx, cx,
+                                    noise_sigma=0.002, rng=rng)
+        d[rng.random(d.shape) > 0.6] = 0
+        frames.append(d.astype(np.uint16))
+    other = synth.frustum_pair(1500, seed=3, rot_deg=(0, 1, 0), shift=(0.01, 0, 0))["source"]
+    Rs = binding.make_rotation_matrix(0.4, -0.3, 0.2)
+    ts = np.array([0.02, -0.01, 0.015], np.float32)
+    camt = np.full(3, 5, np.float32)
+
+    def run(c, script):
+        out = []
+        for k, ops in enumerate(script, start=1):
+            c.backproject_pair(frames[k], frames[k - 1] if k == 1 else None, R=np.eye(3, dtype=np.float32), t=camt, fx=fx, cx=cx)
+            for op in ops:
+                if op == "align":
+                    T, st, rc = c.align(max_iterations=8, threshold=1e-5)
+                    out.append((T.tobytes(), st.iterations, st.final_pairs, rc, c.get_source().tobytes()))
+                elif op == "transform":
+                    c.transform_source(Rs, ts)
+                elif op == "commit":
+                    c.commit_source()
+                elif op == "reset":
+                    c.reset_source()
+                elif op == "set":
+                    c.set_source(other + 5)
+                elif op == "nn":
+                    c.nn(binding.NN_GRID, fetch=False)
+        return out
+
+    script = [["align", "align"], ["transform", "align", "reset", "align"], ["transform", "commit", "align", "nn", "align"],
+              ]
+    script2 = [["nn", "align"], ["set", "align", "transform", "commit", "align"], ["reset", "transform", "align"]]
+    monkeypatch.setenv("ICPK_PRISTINE_SKIP", "0")
+    with binding.Context(0) as c:
+        want = run(c, script) + run(c, script2)
+    monkeypatch.setenv("ICPK_PRISTINE_SKIP", "1")
+    with binding.Context(0) as c:
+        got = run(c, script) + run(c, script2)
+    assert len(got) == len(want) == 10
+    for k, (g, w) in enumerate(zip(got, want)):
+        assert g == w, k
+
+
 def test_backproject_pair_empty_frames_and_bad_arguments():
     z = np.zeros((24, 40), np.uint16)
     d = z.copy()
