@@ -835,6 +835,8 @@ static icpk_ctx* make_context(int device_id, const icpk_ctx* parent) {
   ok = ok && hipHostMalloc((void**)&ctx->st_host, sizeof(LoopState), hipHostMallocDefault) == hipSuccess;
   ok = ok && hipHostMalloc((void**)&ctx->progress, 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess;
   ok = ok && hipHostGetDevicePointer((void**)&ctx->progress_dev, ctx->progress, 0) == hipSuccess;
+  ok = ok && hipHostMalloc((void**)&ctx->st_mirror, sizeof(LoopState), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess;
+  ok = ok && hipHostGetDevicePointer((void**)&ctx->st_mirror_dev, ctx->st_mirror, 0) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&ctx->ready_ev, hipEventDisableTiming) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&ctx->group_ev[0], hipEventDisableTiming) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&ctx->group_ev[1], hipEventDisableTiming) == hipSuccess;
@@ -899,6 +901,7 @@ int icpk_create(icpk_ctx** out, int device_id) {
   }
   if (const char* e = std::getenv("ICPK_BATCH_SETUP")) ctx->batch_setup = std::atoi(e);  // 0: per-pair launches; 2: batched launches for single-group host-pointer batches too; 3: as 2, replayed pair by pair
   if (const char* e = std::getenv("ICPK_PRISTINE_SKIP")) ctx->pristine_skip = std::atoi(e) != 0;
+  if (const char* e = std::getenv("ICPK_RESULT_MIRROR")) ctx->result_mirror = std::atoi(e) != 0;
   if (const char* e = std::getenv("ICPK_LOOP_AHEAD")) {  // 0: enqueue every iteration up front
     const int v = std::atoi(e);
     if (v >= 0 && v <= LOOP_MAX_ITER) ctx->loop_ahead = v;
@@ -933,6 +936,7 @@ void icpk_destroy(icpk_ctx* ctx) {
   if (ctx->slot_states) (void)hipFree(ctx->slot_states);
   if (ctx->slot_states_host) (void)hipHostFree(ctx->slot_states_host);
   if (ctx->progress) (void)hipHostFree(ctx->progress);
+  if (ctx->st_mirror) (void)hipHostFree(ctx->st_mirror);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -1121,13 +1125,14 @@ static int loop_nsum(const icpk_params* p) {
 }
 
 // initial LoopState -> device (on ctx->stream), stop flags armed
-static int device_loop_begin(icpk_ctx* ctx, const icpk_params* p, bool throttled = false) {
+static int device_loop_begin(icpk_ctx* ctx, const icpk_params* p, bool throttled = false, bool mirror = false) {
   LoopInitArgs a{};
   a.st = ctx->st_dev;
-  if (throttled) {
+  if (throttled || mirror) {
     ctx->loop_epoch = (ctx->loop_epoch % 1000000) + 1;  // (<< 10 must fit an int)
     a.epoch = ctx->loop_epoch;
     a.progress = ctx->progress_dev;
+    a.mirror = mirror ? ctx->st_mirror_dev : nullptr;
   }
   a.max_iterations = p->max_iterations;
   a.min_pairs = p->min_pairs;
@@ -1155,9 +1160,10 @@ static void device_loop_disarm(icpk_ctx* ctx) {
 }
 
 // after the LoopState has landed in ctx->st_host: outputs of the alignment
-static int device_loop_finish(icpk_ctx* ctx, const icpk_params* p, float T_out[16], icpk_stats* stats) {
+static int device_loop_finish(icpk_ctx* ctx, const icpk_params* p, float T_out[16], icpk_stats* stats,
+                              const LoopState* h = nullptr) {
   device_loop_disarm(ctx);
-  const LoopState* h = ctx->st_host;
+  if (!h) h = ctx->st_host;
   // the associations of the last EXECUTED sweep are the result
   const int k = h->sweeps;
   if (k >= 1 && k <= (int)ctx->best_of_sweep.size()) {
@@ -1197,12 +1203,14 @@ static int device_loop_finish(icpk_ctx* ctx, const icpk_params* p, float T_out[1
 // host side of LoopState::progress: returns once `steps` loop steps have run on the device or the loop has
 // exited.  Spins (the wait is a fraction of one iteration), yields when a sweep is long, and looks at the
 // stream now and then so that a faulted kernel ends the wait with an error instead of hanging the caller.
+// steps < 0: returns once the loop's outputs have landed in ctx->st_mirror (progress word 2).
 static int wait_loop_progress(icpk_ctx* ctx, int steps, bool* exited) {
   volatile int* pr = ctx->progress;
   const int e = ctx->loop_epoch;
   auto look = [&]() -> int {  // 1: the loop has exited, 2: `steps` steps have run, 0: neither yet
+    if (steps < 0) return __atomic_load_n(&pr[2], __ATOMIC_ACQUIRE) == ((e << 1) | 1) ? 1 : 0;
     const int w0 = __atomic_load_n(&pr[0], __ATOMIC_ACQUIRE), w1 = pr[1];
-    if (w1 == ((e << 1) | 1)) return 1;
+    if ((w1 >> 2) == e && (w1 & 1)) return 1;
     return ((w0 >> 10) == e && (w0 & 1023) >= steps) ? 2 : 0;
   };
   auto t_query = std::chrono::steady_clock::now() + std::chrono::milliseconds(20);
@@ -1258,7 +1266,10 @@ static int align_device_loop(icpk_ctx* ctx, const icpk_params* p, float T_out[16
   // a loop that may leave early is enqueued loop_ahead iterations ahead of the device, not all at once
   const int ahead = ctx->loop_ahead;
   const bool throttled = !p->fixed_iterations && !prof && ahead > 0 && p->max_iterations > ahead;
-  int rc = device_loop_begin(ctx, p, throttled);
+  // the outputs come back through the host-visible mirror the last step writes (LoopState::mirror): no copy kernel,
+  // and in a throttled loop no stream wait either -- the call returns when the deciding step has run
+  const bool mirror = ctx->result_mirror && !prof;
+  int rc = device_loop_begin(ctx, p, throttled, mirror);
   if (rc) return rc;
 
   int nsweep = 0;
@@ -1268,7 +1279,8 @@ static int align_device_loop(icpk_ctx* ctx, const icpk_params* p, float T_out[16
   auto gone = [&]() -> bool {
     if (!throttled) return false;
     const volatile int* pr = ctx->progress;
-    return pr[1] == ((ctx->loop_epoch << 1) | 1);
+    const int w1 = pr[1];
+    return (w1 >> 2) == ctx->loop_epoch && (w1 & 1);
   };
   auto sweep = [&]() -> int {
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -1318,14 +1330,34 @@ static int align_device_loop(icpk_ctx* ctx, const icpk_params* p, float T_out[16
     rc = sweep();  // icp.cpp:255
     if (rc) return rc;
   }
-  launch_loop_step(ctx->partial, ctx->pcount, B, nsum, ctx->st_dev, 1, ctx->stream);
+  // a step that set `done` has published the outputs already: the statistics-only step would be a no-op launch
+  bool done_seen = false;
+  if (throttled && mirror) {
+    const int w1 = ((const volatile int*)ctx->progress)[1];
+    done_seen = (w1 >> 2) == ctx->loop_epoch && (w1 & 2);
+  }
+  if (!done_seen) launch_loop_step(ctx->partial, ctx->pcount, B, nsum, ctx->st_dev, 1, ctx->stream);
   if (loop_rec(ctx))  // the caller-order planes and keys the grid sweeps did not keep current, once
     launch_grid_unpack(ctx->qm4, ctx->rec, ctx->src.n, ctx->src.x(), ctx->src.y(), ctx->src.z(), ctx->best, ctx->stream);
   ICPK_HIP(ctx, hipGetLastError());
-  ICPK_HIP(ctx, hipMemcpyAsync(ctx->st_host, ctx->st_dev, sizeof(LoopState), hipMemcpyDeviceToHost, ctx->stream));
-  ICPK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  const LoopState* result = nullptr;
+  if (mirror) {
+    if (throttled) {  // (what is still enqueued -- a no-op sweep, the unpack -- is stream-ordered before whatever comes next)
+      bool ready = false;
+      rc = wait_loop_progress(ctx, -1, &ready);
+      if (rc) return rc;
+    } else {
+      ICPK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      if (__atomic_load_n(&ctx->progress[2], __ATOMIC_ACQUIRE) != ((ctx->loop_epoch << 1) | 1))
+        return fail(ctx, ICPK_E_HIP, "device loop ended without publishing its result");
+    }
+    result = ctx->st_mirror;
+  } else {
+    ICPK_HIP(ctx, hipMemcpyAsync(ctx->st_host, ctx->st_dev, sizeof(LoopState), hipMemcpyDeviceToHost, ctx->stream));
+    ICPK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
 
-  rc = device_loop_finish(ctx, p, T_out, stats);
+  rc = device_loop_finish(ctx, p, T_out, stats, result);
   if (stats) {
     stats->nn_timed_launches = (int32_t)ev_nn.size();
     if (prof && nev >= 2) {
@@ -2293,11 +2325,39 @@ int icpk_backproject_pair(icpk_ctx* ctx, const uint16_t* depth_source, const uin
     std::memcpy(rt.t, t, sizeof(rt.t));
   }
   int* n_dev = ctx->bp_counts + 2 * per_image;
+  // the one host wait: both counts (and both images consumed).  The scan writes them into pinned, mapped words as
+  // well (progress words 4, 5), the host spins on those and returns while the scatter is still running -- whatever
+  // comes next is stream-ordered behind it.  ICPK_RESULT_MIRROR=0: copy them back and wait for the stream.
+  volatile int* const nw = ctx->progress + 4;
+  nw[0] = nw[1] = -1;
+  __atomic_thread_fence(__ATOMIC_SEQ_CST);
   launch_backproject_pair(b, rows, cols, fx, cx, offset ? offset[0] : 0.f, offset ? offset[1] : 0.f,
-                          offset ? offset[2] : 0.f, rt, R != nullptr, n_dev, ctx->stream);
+                          offset ? offset[2] : 0.f, rt, R != nullptr, n_dev, ctx->result_mirror ? ctx->progress_dev + 4 : nullptr,
+                          ctx->stream);
   ICPK_HIP(ctx, hipGetLastError());
-  ICPK_HIP(ctx, hipMemcpyAsync(ctx->bp_n_host, n_dev, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-  ICPK_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the one host wait: both counts (and both images consumed)
+  if (ctx->result_mirror) {
+    auto t_query = std::chrono::steady_clock::now() + std::chrono::milliseconds(20);
+    for (unsigned spin = 1; nw[0] < 0 || nw[1] < 0; ++spin) {
+      __builtin_ia32_pause();
+      if ((spin & 0x3ff) != 0) continue;
+      std::this_thread::yield();
+      const auto now = std::chrono::steady_clock::now();
+      if (now < t_query) continue;
+      t_query = now + std::chrono::milliseconds(20);
+      const hipError_t q = hipStreamQuery(ctx->stream);  // (a faulted kernel must end the wait)
+      if (q == hipSuccess) {
+        if (nw[0] < 0 || nw[1] < 0) return icpk_host_fail(ctx, ICPK_E_HIP, "back-projection ended without its counts");
+        break;
+      }
+      if (q != hipErrorNotReady) return icpk_host_fail(ctx, ICPK_E_HIP, hipGetErrorString(q));
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    ctx->bp_n_host[0] = nw[0];
+    ctx->bp_n_host[1] = nw[1];
+  } else {
+    ICPK_HIP(ctx, hipMemcpyAsync(ctx->bp_n_host, n_dev, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    ICPK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
   ctx->src0.n = ctx->src.n = ctx->bp_n_host[0];
   ctx->tgt.n = ctx->bp_n_host[1];
   ctx->src_pristine = true;  // (the scatter wrote the committed and the working copy of the source at once)

@@ -183,9 +183,13 @@ struct LoopState {
   // exited.  With a loop that may exit early (threshold mode) the host enqueues only a couple of
   // iterations ahead of them instead of all max_iterations: every launch after the exit is a no-op that
   // still costs its dispatch (~3 us each: 100 us for the reference's 16 / 1e-4 setting leaving after 5).
-  // Both words carry `epoch` ([0] = epoch << 10 | steps, [1] = epoch << 1 | exited), so that words still
+  // Both words carry `epoch` ([0] = epoch << 10 | steps, [1] = epoch << 2 | done << 1 | exited), so that words still
   // being written by an alignment that was abandoned on an error are never taken for this one's.
   int* progress;
+  // host-visible (pinned, mapped) copy of the OUTPUT fields of this struct or nullptr: the step that ends the loop
+  // writes them there and then sets progress[2] = epoch << 1 | 1 with a system-scope release, so the host has the
+  // result the moment the loop ends -- no copy kernel, no stream wait (trace entries go there as they are made)
+  LoopState* mirror;
   Rt rt;                     // transform to apply in this iteration
   double Rd[9];              // rt.R widened (exact) by the step: the sweeps' fused K3 takes the rotation as float64 scalars
   float Trot[9];             // icp.cpp:227-233
@@ -286,7 +290,7 @@ struct BpPair {
   BpImage im[2];
 };
 void launch_backproject_pair(const BpPair& b, int rows, int cols, float fx, float cx, float ox, float oy, float oz,
-                             const Rt& rt, int posed, int* n_out, hipStream_t s);
+                             const Rt& rt, int posed, int* n_out, int* n_host, hipStream_t s);
 
 // kernels_frontend.hip
 // order-preserving split of a sweep's result into accepted pairs and rejected queries
@@ -319,6 +323,7 @@ struct IngestArgs {
 struct LoopInitArgs {
   LoopState* st;
   int* progress;
+  LoopState* mirror;
   int max_iterations, min_pairs, solve, fixed_iterations;
   float threshold;
   int epoch;

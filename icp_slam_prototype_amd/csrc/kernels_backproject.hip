@@ -77,8 +77,12 @@ __global__ void bp_scan_kernel(int* __restrict__ block_counts, int nblocks, int*
   bp_scan_body(block_counts, nblocks, n_out);
 }
 
-__global__ void bp_scan_pair_kernel(const BpPair b, int nblocks, int* __restrict__ n_out) {
+// n_host: pinned, mapped words the host spins on (icpk_backproject_pair returns as soon as both totals are known,
+// while the scatter still runs) or nullptr
+__global__ void bp_scan_pair_kernel(const BpPair b, int nblocks, int* __restrict__ n_out, int* __restrict__ n_host) {
   bp_scan_body(b.im[blockIdx.x].counts, nblocks, n_out + blockIdx.x);
+  if (n_host && threadIdx.x == 0)  // (the thread that wrote the total)
+    __hip_atomic_store(n_host + blockIdx.x, b.im[blockIdx.x].counts[nblocks], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // Surface normal of pixel (r, c) -- point-to-plane extension (not in the reference,
@@ -242,11 +246,11 @@ __global__ __launch_bounds__(BP_THREADS) void bp_scatter_pair_kernel(const BpPai
 }
 
 void launch_backproject_pair(const BpPair& b, int rows, int cols, float fx, float cx, float ox, float oy, float oz,
-                             const Rt& rt, int posed, int* n_out, hipStream_t s) {
+                             const Rt& rt, int posed, int* n_out, int* n_host, hipStream_t s) {
   const int npix = rows * cols;
   const int nblocks = (npix + BP_BLOCK - 1) / BP_BLOCK;
   hipLaunchKernelGGL(bp_count_pair_kernel, dim3(nblocks, 2), dim3(BP_THREADS), 0, s, b, npix);
-  hipLaunchKernelGGL(bp_scan_pair_kernel, dim3(2), dim3(256), 0, s, b, nblocks, n_out);
+  hipLaunchKernelGGL(bp_scan_pair_kernel, dim3(2), dim3(256), 0, s, b, nblocks, n_out, n_host);
   hipLaunchKernelGGL(bp_scatter_pair_kernel, dim3(nblocks, 2), dim3(BP_THREADS), 0, s, b, npix, cols, nblocks, fx, cx, ox,
                      oy, oz, rt, posed);
 }

@@ -109,10 +109,27 @@ __device__ __forceinline__ void publish_progress(LoopState* __restrict__ st) {
   int* pr = st->progress;
   if (pr) {
     const int e = st->epoch;
-    __hip_atomic_store(pr + 1, (e << 1) | ((st->done | st->stop_after_transform) != 0), __ATOMIC_RELAXED,
+    __hip_atomic_store(pr + 1, (e << 2) | ((st->done != 0) << 1) | ((st->done | st->stop_after_transform) != 0), __ATOMIC_RELAXED,
                        __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(pr, (e << 10) | k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
+}
+
+// thread 0, when the outputs are final (the step that sets `done`, or the statistics-only step behind the last sweep):
+// the host-visible copy (LoopState::mirror), then its ready word with a system-scope release -- once per alignment
+__device__ __forceinline__ void publish_result(LoopState* __restrict__ st) {
+  LoopState* __restrict__ m = st->mirror;
+  if (!m) return;
+  m->done = st->done;
+  m->iterations = st->iterations;
+  m->status = st->status;
+  m->sweeps = st->sweeps;
+  m->pairs = st->pairs;
+  m->mse = st->mse;
+  for (int k = 0; k < 9; ++k) m->Trot[k] = st->Trot[k];
+  for (int k = 0; k < 3; ++k) m->offset[k] = st->offset[k];
+  for (int k = 0; k < 12; ++k) m->Tk[k] = st->Tk[k];
+  __hip_atomic_store(st->progress + 2, (st->epoch << 1) | 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 template <int NS, int NACT = NS>
@@ -145,6 +162,7 @@ __device__ __forceinline__ void loop_step_body(const double* __restrict__ partia
   if (stop_after) {  // the fallback motion has been applied by the previous transform
     if (threadIdx.x == 0) {
       st->done = 1;
+      publish_result(st);
       publish_progress(st);
     }
     return;
@@ -159,10 +177,14 @@ __device__ __forceinline__ void loop_step_body(const double* __restrict__ partia
   }
   st->pairs = npairs;
   st->mse = mse;
-  if (stats_only) return;
+  if (stats_only) {
+    publish_result(st);
+    return;
+  }
 
   if (!((fixed || mse > threshold) && i < max_iterations)) {  // icp.cpp:155
     st->done = 1;
+    publish_result(st);
     publish_progress(st);
     return;
   }
@@ -180,6 +202,11 @@ __device__ __forceinline__ void loop_step_body(const double* __restrict__ partia
   }
   st->trace_pairs[i] = (int)npairs;
   st->trace_mse[i] = mse;
+  LoopState* __restrict__ mir = st->mirror;
+  if (mir) {
+    mir->trace_pairs[i] = (int)npairs;
+    mir->trace_mse[i] = mse;
+  }
   float Rrec[9], trec[3];
   STEP_STAMP(i, 2);
   if (NS == NP2L) {
@@ -187,6 +214,7 @@ __device__ __forceinline__ void loop_step_body(const double* __restrict__ partia
     if (!solve_p2l(sums, Rd, td)) {
       st->status = 2;  // ICPK_W_DEGENERATE
       st->done = 1;
+      publish_result(st);
       publish_progress(st);
       return;
     }
@@ -234,6 +262,10 @@ __device__ __forceinline__ void loop_step_body(const double* __restrict__ partia
   for (int k = 0; k < 9; ++k) st->Rd[k] = (double)st->rt.R[k];
   for (int k = 0; k < 9; ++k) st->trace_R[9 * i + k] = Rrec[k];
   for (int k = 0; k < 3; ++k) st->trace_t[3 * i + k] = trec[k];
+  if (mir) {
+    for (int k = 0; k < 9; ++k) mir->trace_R[9 * i + k] = Rrec[k];
+    for (int k = 0; k < 3; ++k) mir->trace_t[3 * i + k] = trec[k];
+  }
   st->iterations = i + 1;  // icp.cpp:257 (the sweep that follows is already enqueued)
   publish_progress(st);
   STEP_STAMP(i, 4);
@@ -271,6 +303,7 @@ __device__ __forceinline__ void loop_init_body(const LoopInitArgs& a) {
   st->threshold = a.threshold;
   st->epoch = a.epoch;
   st->progress = a.progress;
+  st->mirror = a.mirror;
   for (int k = 0; k < 9; ++k) st->last_rotation[k] = a.last_rotation[k];
   for (int k = 0; k < 3; ++k) st->last_translation[k] = a.last_translation[k];
 }
