@@ -332,6 +332,15 @@ int enqueue_cell_order(icpk_ctx* ctx, bool with_points) {
 
 int ensure_query_points(icpk_ctx* ctx, int nq);
 
+// the deferred initial LoopState of a device loop (device_loop_begin), if no set-up launch has carried it
+int flush_loop_init(icpk_ctx* ctx) {
+  if (!ctx->init_pending) return ICPK_OK;
+  ctx->init_pending = false;
+  launch_loop_init(ctx->pending_init, ctx->stream);
+  ICPK_HIP(ctx, hipGetLastError());
+  return ICPK_OK;
+}
+
 // A FRESH pair (new target, new source, no seeds: every frame of the drop-in path): the target's grid and the
 // query order in 6 launches instead of 10 -- the two counting sorts run side by side (cell slots of both clouds in one
 // launch, both scans in two, both scatters in one), each with its own count table.  Same kernels' bodies as
@@ -378,8 +387,15 @@ int build_grid_and_order(icpk_ctx* ctx) {
   int* tslot = ctx->sort_vals;
   int* qcell = reinterpret_cast<int*>(ctx->sort_keys);
   int* qslot = ctx->sort_vals2;
-  launch_grid_bounds(ctx->tgt.x(), ctx->tgt.y(), ctx->tgt.z(), nt, ctx->grid_bounds, ctx->stream);
-  launch_grid_info(ctx->grid_bounds, nt, ctx->grid_ppc, ctx->grid_xdiv, ctx->grid_max_cells, ctx->grid_info, ctx->stream);
+  if (!ctx->grid_ticket) {
+    ICPK_HIP(ctx, hipMalloc((void**)&ctx->grid_ticket, sizeof(int)));
+    ICPK_HIP(ctx, hipMemsetAsync(ctx->grid_ticket, 0, sizeof(int), ctx->stream));
+  }
+  // bounds + geometry (+ the pending initial LoopState of the alignment being enqueued) in ONE launch
+  launch_grid_begin(ctx->tgt.x(), ctx->tgt.y(), ctx->tgt.z(), nt, ctx->grid_bounds, ctx->grid_ppc, ctx->grid_xdiv,
+                    ctx->grid_max_cells, ctx->grid_info, ctx->init_pending ? &ctx->pending_init : nullptr, ctx->grid_ticket,
+                    ctx->stream);
+  ctx->init_pending = false;
   ctx->qcount_dirty = ctx->qcount2_dirty = true;
   SetupBatchOf<QslotArgs> qb{};
   qb.p[0] = QslotArgs{ctx->tgt.x(), ctx->tgt.y(), ctx->tgt.z(), ctx->grid_info, ctx->qcount, tcell, tslot, nt, 0};
@@ -588,6 +604,7 @@ int enqueue_nn(icpk_ctx* ctx, int nn_mode, hipEvent_t ev0 = nullptr, hipEvent_t 
   };
   NnArgs a = base_nn_args(ctx);
   const int ntiles = a.nt_pad / NN_TILE;
+  if (nn_mode != ICPK_NN_GRID && (rc = flush_loop_init(ctx))) return rc;  // (their fills and kernels look at the state)
   if (nn_mode == ICPK_NN_EXACT) {
     a.tiles_per_chunk = chunking((nq + NN_THREADS - 1) / NN_THREADS, ntiles);
     a.best = ctx->best;
@@ -600,6 +617,7 @@ int enqueue_nn(icpk_ctx* ctx, int nn_mode, hipEvent_t ev0 = nullptr, hipEvent_t 
     int recheck = 0;
     rc = prepare_sorted_sweep(ctx, nn_mode, a, bx, recheck);
     if (rc) return rc;
+    if ((rc = flush_loop_init(ctx))) return rc;  // (unless the set-up's first launch has carried it)
     if ((rc = mark(ev0))) return rc;
     if (nn_mode == ICPK_NN_GRID) {
       launch_nn_grid(grid_sweep_args(ctx, a, bx), grid_slices_for(ctx, nq), recheck, ctx->stream);
@@ -937,6 +955,7 @@ void icpk_destroy(icpk_ctx* ctx) {
   if (ctx->slot_states_host) (void)hipHostFree(ctx->slot_states_host);
   if (ctx->progress) (void)hipHostFree(ctx->progress);
   if (ctx->st_mirror) (void)hipHostFree(ctx->st_mirror);
+  if (ctx->grid_ticket) (void)hipFree(ctx->grid_ticket);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -1125,7 +1144,10 @@ static int loop_nsum(const icpk_params* p) {
 }
 
 // initial LoopState -> device (on ctx->stream), stop flags armed
-static int device_loop_begin(icpk_ctx* ctx, const icpk_params* p, bool throttled = false, bool mirror = false) {
+// defer: the launch is left to the first set-up launch that can carry it (build_grid_and_order) or, failing that, to
+// flush_loop_init right before the first kernel that reads the state
+static int device_loop_begin(icpk_ctx* ctx, const icpk_params* p, bool throttled = false, bool mirror = false,
+                             bool defer = false) {
   LoopInitArgs a{};
   a.st = ctx->st_dev;
   if (throttled || mirror) {
@@ -1141,8 +1163,13 @@ static int device_loop_begin(icpk_ctx* ctx, const icpk_params* p, bool throttled
   a.threshold = p->threshold;
   std::memcpy(a.last_rotation, p->last_rotation, sizeof(a.last_rotation));
   std::memcpy(a.last_translation, p->last_translation, sizeof(a.last_translation));
-  launch_loop_init(a, ctx->stream);  // (values travel in the kernel arguments: no staging copy)
-  ICPK_HIP(ctx, hipGetLastError());
+  if (defer) {
+    ctx->pending_init = a;
+    ctx->init_pending = true;
+  } else {
+    launch_loop_init(a, ctx->stream);  // (values travel in the kernel arguments: no staging copy)
+    ICPK_HIP(ctx, hipGetLastError());
+  }
   const int nsum = loop_nsum(p);
   ctx->loop_nact = nsum == NSUM_REF ? NSUM_REF : NSUM;
   // the stop flags are only meaningful while this alignment is being enqueued
@@ -1154,6 +1181,7 @@ static int device_loop_begin(icpk_ctx* ctx, const icpk_params* p, bool throttled
 }
 
 static void device_loop_disarm(icpk_ctx* ctx) {
+  ctx->init_pending = false;
   ctx->stop = nullptr;
   ctx->st_active = nullptr;
   ctx->grid_chain = false;
@@ -1269,7 +1297,7 @@ static int align_device_loop(icpk_ctx* ctx, const icpk_params* p, float T_out[16
   // the outputs come back through the host-visible mirror the last step writes (LoopState::mirror): no copy kernel,
   // and in a throttled loop no stream wait either -- the call returns when the deciding step has run
   const bool mirror = ctx->result_mirror && !prof;
-  int rc = device_loop_begin(ctx, p, throttled, mirror);
+  int rc = device_loop_begin(ctx, p, throttled, mirror, /*defer=*/p->nn_mode == ICPK_NN_GRID && !prof);
   if (rc) return rc;
 
   int nsweep = 0;
@@ -1307,6 +1335,7 @@ static int align_device_loop(icpk_ctx* ctx, const icpk_params* p, float T_out[16
   };
   rc = sweep();  // icp.cpp:98
   if (rc) return rc;
+  if ((rc = flush_loop_init(ctx))) return rc;  // (normally carried by the set-up or flushed before the sweep already)
   for (int i = 0; i < p->max_iterations; ++i) {
     if (throttled && i >= ahead) {
       bool exited = false;

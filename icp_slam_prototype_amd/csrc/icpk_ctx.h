@@ -76,6 +76,9 @@ struct icpk_ctx {
   LoopState* st_mirror = nullptr;      // pinned + mapped: the loop's outputs as the device writes them at its end (LoopState::mirror)
   LoopState* st_mirror_dev = nullptr;  // the same memory as the device addresses it
   bool result_mirror = true;           // ICPK_RESULT_MIRROR=0: copy the state back and wait for the stream instead (diagnostic)
+  icpk::LoopInitArgs pending_init{};         // device_loop_begin(defer): the initial LoopState not launched yet
+  bool init_pending = false;
+  int* grid_ticket = nullptr;          // grid_begin_kernel's arrival counter (zero between launches)
   bool src_pristine = false;     // the working source equals the committed one (see copy_src0_to_src)
   bool pristine_skip = true;     // ICPK_PRISTINE_SKIP=0: always copy (diagnostic)
   int loop_ahead = 1;            // iterations kept enqueued ahead of the device in a loop that may exit early

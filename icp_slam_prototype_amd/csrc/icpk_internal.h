@@ -395,6 +395,8 @@ template <typename A>
 struct SetupBatchOf {
   A p[BATCH_MAX];
 };
+void launch_grid_begin(const float* x, const float* y, const float* z, int n, float* fb, float ppc, int xdiv, int max_cells,
+                       GridInfo* g, const LoopInitArgs* init, int* ticket, hipStream_t s);
 void launch_loop_init(const LoopInitArgs& a, hipStream_t s);
 // one launch per recorded step for `count` pairs, in recording order; returns false if the sequences differ
 // (nothing launched then: replay them with replay_setup)

@@ -17,6 +17,7 @@
 #include <type_traits>
 
 #include "icpk_internal.h"
+#include "loop_init.h"
 #include "nn_device.h"
 #include "wave_sum.h"
 
@@ -137,6 +138,31 @@ __device__ __forceinline__ void grid_info_body(const float* __restrict__ fbp, in
 }
 
 __global__ void grid_info_kernel(const InfoArgs a) { grid_info_body(a.fb, a.nparts, a.n, a.ppc, a.xdiv, a.max_cells, a.g); }
+
+// The first launch of a fresh frame pair's set-up (build_grid_and_order): the bounds pass, and behind it -- in the
+// workgroup that draws the last ticket -- the grid's geometry; workgroup 0 writes the initial LoopState of the
+// alignment on the side (has_init).  One launch instead of three on a path that is a chain of tiny dependent
+// kernels, each of which costs ~4 us of dispatch on top of its ~3 us of work.  The hand-off is the placement-
+// independent one: partial boxes stored, agent-scope release, ticket; the last arriver acquires and reads them.
+__global__ __launch_bounds__(1024) void grid_begin_kernel(const BoundsArgs a, const InfoArgs info, const LoopInitArgs li,
+                                                          const int has_init, int* __restrict__ ticket) {
+  if (has_init && blockIdx.x == 0) loop_init_body(li);
+  grid_bounds_body(a, blockIdx.x);
+  __shared__ int s_last;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    const int t = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = t == a.nparts - 1;
+    if (s_last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (ready for the next launch)
+    }
+  }
+  __syncthreads();
+  if (!s_last || threadIdx.x >= 64) return;
+  grid_info_body(info.fb, info.nparts, info.n, info.ppc, info.xdiv, info.max_cells, info.g);
+}
 __global__ void grid_info_batch_kernel(const SetupBatchOf<InfoArgs> b) {
   const InfoArgs& a = b.p[blockIdx.x];
   grid_info_body(a.fb, a.nparts, a.n, a.ppc, a.xdiv, a.max_cells, a.g);
@@ -415,6 +441,13 @@ void launch_grid_bounds_batch(const SetupBatchOf<BoundsArgs>& b, int count, hipS
   int m = 0;
   for (int k = 0; k < count; ++k) m = b.p[k].nparts > m ? b.p[k].nparts : m;
   if (count > 0 && m > 0) hipLaunchKernelGGL(grid_bounds_batch_kernel, dim3(m, count), dim3(1024), 0, s, b);
+}
+void launch_grid_begin(const float* x, const float* y, const float* z, int n, float* fb, float ppc, int xdiv, int max_cells,
+                       GridInfo* g, const LoopInitArgs* init, int* ticket, hipStream_t s) {
+  const BoundsArgs a{x, y, z, fb, n, grid_bounds_parts(n)};
+  const InfoArgs info{fb, g, a.nparts, n, ppc, xdiv < 1 ? 1 : xdiv, max_cells < 64 ? 64 : max_cells, 0};
+  hipLaunchKernelGGL(grid_begin_kernel, dim3(a.nparts), dim3(1024), 0, s, a, info, init ? *init : LoopInitArgs{}, init ? 1 : 0,
+                     ticket);
 }
 void launch_grid_info(const float* fb, int n, float ppc, int xdiv, int max_cells, GridInfo* g, hipStream_t s) {
   const InfoArgs a{fb, g, grid_bounds_parts(n), n, ppc, xdiv < 1 ? 1 : xdiv, max_cells < 64 ? 64 : max_cells, 0};
