@@ -32,6 +32,7 @@ int fail(icpk_ctx* ctx, int code, const char* msg) {
 
 int ensure_cloud(icpk_ctx* ctx, Cloud& c, int n) {
   if (ctx && (&c == &ctx->src0 || &c == &ctx->src)) ctx->src_pristine = false;  // (about to be resized or rewritten)
+  if (ctx && (&c == &ctx->src0 || &c == &ctx->tgt)) ctx->have_pix_seed = false;  // (other points than the pixel maps describe)
   const int cap = round_up(n < 1 ? 1 : n, NN_TILE);
   if (cap > c.cap) {
     if (c.base) ICPK_HIP(ctx, hipFree(c.base));
@@ -406,8 +407,10 @@ int build_grid_and_order(icpk_ctx* ctx) {
   sb.p[1] = ScanArgs{ctx->qcount2, ctx->qstart, ctx->scan_bsum2, ctx->grid_info, 1, 0};
   launch_grid_scan_batch(sb, 2, ctx->stream);
   const TscatterArgs ta{ctx->tgt.x(), ctx->tgt.y(), ctx->tgt.z(), tcell, tslot, ctx->cell_start, ctx->t4, ctx->o4, nt, 0};
+  const bool pix = ctx->have_pix_seed && ctx->pixel_seeds;
   const QscatterArgs qa{qcell,        qslot,        ctx->qstart,  ctx->qperm,   ctx->src.x(), ctx->src.y(), ctx->src.z(), ctx->tgt.x(),
-                        ctx->tgt.y(), ctx->tgt.z(), ctx->qm4,     ctx->sp_in,   ctx->seed_m,  nq,           0};
+                        ctx->tgt.y(), ctx->tgt.z(), ctx->qm4,     ctx->sp_in,   ctx->seed_m,  nq,           0,
+                        pix ? ctx->pix_src : nullptr, pix ? ctx->pix_tidx : nullptr, ctx->pix_rows, ctx->pix_cols};
   launch_grid_tqscatter(ta, qa, ctx->stream);
   ICPK_HIP(ctx, hipGetLastError());
   ctx->qcount_dirty = ctx->qcount2_dirty = false;
@@ -919,6 +922,8 @@ int icpk_create(icpk_ctx** out, int device_id) {
   }
   if (const char* e = std::getenv("ICPK_BATCH_SETUP")) ctx->batch_setup = std::atoi(e);  // 0: per-pair launches; 2: batched launches for single-group host-pointer batches too; 3: as 2, replayed pair by pair
   if (const char* e = std::getenv("ICPK_PRISTINE_SKIP")) ctx->pristine_skip = std::atoi(e) != 0;
+  if (const char* e = std::getenv("ICPK_PIXEL_SEEDS")) ctx->pixel_seeds = std::atoi(e) != 0;
+  if (const char* e = std::getenv("ICPK_ZERO_COPY_UPLOAD")) ctx->zero_copy_upload = std::atoi(e) != 0;
   if (const char* e = std::getenv("ICPK_RESULT_MIRROR")) ctx->result_mirror = std::atoi(e) != 0;
   if (const char* e = std::getenv("ICPK_LOOP_AHEAD")) {  // 0: enqueue every iteration up front
     const int v = std::atoi(e);
@@ -956,6 +961,9 @@ void icpk_destroy(icpk_ctx* ctx) {
   if (ctx->progress) (void)hipHostFree(ctx->progress);
   if (ctx->st_mirror) (void)hipHostFree(ctx->st_mirror);
   if (ctx->grid_ticket) (void)hipFree(ctx->grid_ticket);
+  if (ctx->stage_depth) (void)hipHostFree(ctx->stage_depth);
+  if (ctx->pix_tidx) (void)hipFree(ctx->pix_tidx);
+  if (ctx->pix_src) (void)hipFree(ctx->pix_src);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
 }
@@ -2332,8 +2340,35 @@ int icpk_backproject_pair(icpk_ctx* ctx, const uint16_t* depth_source, const uin
   uint16_t* const flt_t = ctx->depth_flt + (size_t)tslot * npix;
   const size_t bytes = (size_t)npix * sizeof(uint16_t);
   ctx->frame_slot = -1;  // (nothing is resident until this call has enqueued everything)
-  ICPK_HIP(ctx, hipMemcpyAsync(raw_s, depth_source, bytes, hipMemcpyHostToDevice, ctx->stream));
-  if (!resident) ICPK_HIP(ctx, hipMemcpyAsync(raw_t, depth_target, bytes, hipMemcpyHostToDevice, ctx->stream));
+  // The images cross PCIe from the context's own pinned staging buffer, in halves: the copy engine moves one half
+  // while the host copies the next one in.  (Handing the caller's pageable buffer to hipMemcpyAsync leaves the staging
+  // to the runtime -- one blocking copy, then the transfer -- and was seen to take 70 us in one process and 340 us in
+  // the next for the same 614 KB.)  The buffer is free again when this call returns: the counts it waits for are made
+  // from the uploaded images.
+  if (2 * npix > ctx->stage_depth_cap) {
+    if (ctx->stage_depth) ICPK_HIP(ctx, hipHostFree(ctx->stage_depth));
+    ctx->stage_depth = nullptr;
+    ctx->stage_depth_cap = 0;
+    ICPK_HIP(ctx, hipHostMalloc((void**)&ctx->stage_depth, (size_t)2 * npix * sizeof(uint16_t), hipHostMallocDefault));
+    ctx->stage_depth_cap = 2 * npix;
+  }
+  // without the filter the images are not copied at all: the counting pass reads them from the staging buffer
+  const bool zero_copy = !filter && ctx->zero_copy_upload;
+  auto upload = [&](uint16_t* dev, const uint16_t* host, uint16_t* stage) -> int {
+    if (zero_copy) {
+      std::memcpy(stage, host, bytes);
+      return ICPK_OK;
+    }
+    const int parts = npix >= 65536 ? 2 : 1;  // (more parts cost more in copy commands than they hide)
+    for (int k = 0; k < parts; ++k) {
+      const size_t a0 = (size_t)npix * k / parts, a1 = (size_t)npix * (k + 1) / parts;
+      std::memcpy(stage + a0, host + a0, (a1 - a0) * sizeof(uint16_t));
+      ICPK_HIP(ctx, hipMemcpyAsync(dev + a0, stage + a0, (a1 - a0) * sizeof(uint16_t), hipMemcpyHostToDevice, ctx->stream));
+    }
+    return ICPK_OK;
+  };
+  if ((rc = upload(raw_s, depth_source, ctx->stage_depth))) return rc;
+  if (!resident && (rc = upload(raw_t, depth_target, ctx->stage_depth + npix))) return rc;
   const uint16_t *img_s = raw_s, *img_t = raw_t;
   if (filter) {  // SLAM.cpp:229,553-574: the frames are filtered before they are back-projected
     launch_depth_filter(raw_s, flt_s, rows, cols, min_d, max_d, ax, ay, morph != 0, ctx->stream);
@@ -2343,11 +2378,23 @@ int icpk_backproject_pair(icpk_ctx* ctx, const uint16_t* depth_source, const uin
     img_s = flt_s;
     img_t = flt_t;
   }
+  if (npix > ctx->pix_cap) {
+    if (ctx->pix_tidx) ICPK_HIP(ctx, hipFree(ctx->pix_tidx));
+    if (ctx->pix_src) ICPK_HIP(ctx, hipFree(ctx->pix_src));
+    ctx->pix_tidx = ctx->pix_src = nullptr;
+    ctx->pix_cap = 0;
+    ICPK_HIP(ctx, hipMalloc((void**)&ctx->pix_tidx, (size_t)npix * sizeof(int)));
+    ICPK_HIP(ctx, hipMalloc((void**)&ctx->pix_src, (size_t)npix * sizeof(int)));
+    ctx->pix_cap = npix;
+  }
   BpPair b;
+  const uint16_t* stage_dev = nullptr;
+  if (zero_copy) ICPK_HIP(ctx, hipHostGetDevicePointer((void**)&stage_dev, ctx->stage_depth, 0));
   b.im[0] = BpImage{img_s, ctx->src0.x(), ctx->src0.y(), ctx->src0.z(), ctx->src.x(), ctx->src.y(), ctx->src.z(),
-                    ctx->bp_counts, 0.f};
+                    ctx->bp_counts, 0.f, ctx->pix_src, nullptr, zero_copy ? stage_dev : nullptr, raw_s};
   b.im[1] = BpImage{img_t, ctx->tgt.x(), ctx->tgt.y(), ctx->tgt.z(), nullptr, nullptr, nullptr,
-                    ctx->bp_counts + per_image, __builtin_inff()};
+                    ctx->bp_counts + per_image, __builtin_inff(), nullptr, ctx->pix_tidx,
+                    zero_copy && !resident ? stage_dev + npix : nullptr, raw_t};
   Rt rt{};
   if (R) {
     std::memcpy(rt.R, R, sizeof(rt.R));
@@ -2390,6 +2437,9 @@ int icpk_backproject_pair(icpk_ctx* ctx, const uint16_t* depth_source, const uin
   ctx->src0.n = ctx->src.n = ctx->bp_n_host[0];
   ctx->tgt.n = ctx->bp_n_host[1];
   ctx->src_pristine = true;  // (the scatter wrote the committed and the working copy of the source at once)
+  ctx->have_pix_seed = true;  // (... and which pixel every point came from)
+  ctx->pix_rows = rows;
+  ctx->pix_cols = cols;
   ctx->have_src = ctx->have_tgt = true;
   ctx->have_assoc = ctx->have_seed = ctx->have_qperm = false;
   ctx->have_dec = ctx->have_boxes = ctx->have_grid = ctx->have_normals = false;

@@ -79,6 +79,15 @@ struct icpk_ctx {
   icpk::LoopInitArgs pending_init{};         // device_loop_begin(defer): the initial LoopState not launched yet
   bool init_pending = false;
   int* grid_ticket = nullptr;          // grid_begin_kernel's arrival counter (zero between launches)
+  bool zero_copy_upload = true;        // ICPK_ZERO_COPY_UPLOAD=0: copy-engine transfer from the staging buffer instead (diagnostic)
+  uint16_t* stage_depth = nullptr;     // pinned: icpk_backproject_pair's images on their way to the device
+  int stage_depth_cap = 0;
+  int* pix_tidx = nullptr;             // icpk_backproject_pair: the target point of every pixel (-1: none) ...
+  int* pix_src = nullptr;              // ... and the pixel of every source point: image-space seeds of the alignment that follows
+  int pix_cap = 0;
+  bool have_pix_seed = false;          // they describe the clouds the context holds now
+  bool pixel_seeds = true;             // ICPK_PIXEL_SEEDS=0: the reference's literal seed (diagnostic)
+  int pix_rows = 0, pix_cols = 0;
   bool src_pristine = false;     // the working source equals the committed one (see copy_src0_to_src)
   bool pristine_skip = true;     // ICPK_PRISTINE_SKIP=0: always copy (diagnostic)
   int loop_ahead = 1;            // iterations kept enqueued ahead of the device in a loop that may exit early

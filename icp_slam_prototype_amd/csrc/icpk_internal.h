@@ -285,6 +285,15 @@ struct BpImage {
   float *x2, *y2, *z2;
   int* counts;
   float pad;
+  // image-space seeds of the alignment that follows (see QscatterArgs::spix) or nullptr: the pixel of every point
+  // (per point) / the point of every pixel, -1 where the pixel is empty (per pixel)
+  int* pixel_of_point;
+  int* point_of_pixel;
+  // zero-copy upload or nullptr: the image still sits in pinned host memory; the counting pass reads it from there
+  // (one PCIe read per pixel, no copy-engine command in front of the kernels) and leaves the device copy in raw_out,
+  // which `depth` points to for the scatter pass
+  const uint16_t* host_src;
+  uint16_t* raw_out;
 };
 struct BpPair {
   BpImage im[2];
@@ -367,6 +376,14 @@ struct QscatterArgs {
   float4 *qm4, *sp;
   nn_key_t* seed_m;
   int n, pad0;
+  // Seeds from the images the two clouds were back-projected from (icpk_backproject_pair), or nullptr: spix[i] = pixel
+  // of query i, tidx[p] = target point of pixel p or -1.  Consecutive frames of a depth camera put the same surface
+  // within a pixel or two, so the target point of the query's own pixel (or of the nearest occupied pixel of the
+  // 5 x 5 around it) is a seed centimetres from the true match -- instead of the reference's literal element 0, metres
+  // away (icp.cpp:572).  A seed only sets where the search starts: the result is the exact nearest neighbour either way.
+  const int* spix;
+  const int* tidx;
+  int rows, cols;
 };
 enum SetupKind : int { SK_INGEST, SK_LOOP_INIT, SK_BOUNDS, SK_INFO, SK_QSLOT, SK_SCAN, SK_TSCATTER, SK_QSCATTER };
 struct SetupCall {

@@ -17,14 +17,31 @@ constexpr int BP_PER_THREAD = 4;
 constexpr int BP_BLOCK = BP_THREADS * BP_PER_THREAD;  // 1024 pixels per workgroup
 
 __device__ __forceinline__ void bp_count_body(const uint16_t* __restrict__ depth, int npix,
-                                              int* __restrict__ block_counts, const int block) {
+                                              int* __restrict__ block_counts, const int block,
+                                              const uint16_t* __restrict__ host_src = nullptr,
+                                              uint16_t* __restrict__ raw_out = nullptr) {
   const int base = block * BP_BLOCK;
   int c = 0;
+  if (host_src) {  // (all four loads in flight before the first is looked at: they cross PCIe)
+    uint16_t d[BP_PER_THREAD];
 #pragma unroll
-  for (int k = 0; k < BP_PER_THREAD; ++k) {
-    const int p = base + k * BP_THREADS + threadIdx.x;
-    const bool valid = p < npix && depth[p] != 0;
-    c += __popcll(__ballot(valid));
+    for (int k = 0; k < BP_PER_THREAD; ++k) {
+      const int p = base + k * BP_THREADS + threadIdx.x;
+      d[k] = p < npix ? host_src[p] : (uint16_t)0;
+    }
+#pragma unroll
+    for (int k = 0; k < BP_PER_THREAD; ++k) {
+      const int p = base + k * BP_THREADS + threadIdx.x;
+      if (p < npix) raw_out[p] = d[k];
+      c += __popcll(__ballot(d[k] != 0));
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < BP_PER_THREAD; ++k) {
+      const int p = base + k * BP_THREADS + threadIdx.x;
+      const bool valid = p < npix && depth[p] != 0;
+      c += __popcll(__ballot(valid));
+    }
   }
   __shared__ int wc[BP_THREADS / 64];
   if ((threadIdx.x & 63) == 0) wc[threadIdx.x >> 6] = c;
@@ -39,7 +56,8 @@ __global__ __launch_bounds__(BP_THREADS) void bp_count_kernel(const uint16_t* __
 
 // frame-pair entry (icpk_backproject_pair): blockIdx.y = image (0: current frame / source, 1: previous / target)
 __global__ __launch_bounds__(BP_THREADS) void bp_count_pair_kernel(const BpPair b, int npix) {
-  bp_count_body(b.im[blockIdx.y].depth, npix, b.im[blockIdx.y].counts, blockIdx.x);
+  const BpImage& im = b.im[blockIdx.y];
+  bp_count_body(im.depth, npix, im.counts, blockIdx.x, im.host_src, im.raw_out);
 }
 
 // exclusive scan in place; block_counts[nblocks] receives the total
@@ -211,8 +229,13 @@ __global__ __launch_bounds__(BP_THREADS) void bp_scatter_pair_kernel(const BpPai
     int before = 0;
     for (int w = 0; w < wave; ++w) before += wcount[k][w];
     const int rank = off + before + __popcll(mask[k] & ((1ull << lane) - 1ull));
+    if (im.point_of_pixel) {
+      const int p = base + k * BP_THREADS + threadIdx.x;
+      if (p < npix) im.point_of_pixel[p] = dv[k] != 0 ? rank : -1;
+    }
     if (dv[k] != 0) {
       const int p = base + k * BP_THREADS + threadIdx.x;
+      if (im.pixel_of_point) im.pixel_of_point[rank] = p;
       const int r = p / cols, c = p - r * cols;
       const float pz = ((float)dv[k]) / 5000.0f;  // pointcloud.cpp:37-39
       const float px = ((float)c - cx) * pz / fx;

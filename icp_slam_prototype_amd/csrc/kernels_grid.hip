@@ -206,7 +206,32 @@ __device__ __forceinline__ void grid_qscatter_body(const QscatterArgs& a, const 
   a.qperm[ip] = i;
   if (a.qm4) {
     a.qm4[ip] = make_float4(a.qx[i], a.qy[i], a.qz[i], __int_as_float(i));
-    a.sp[ip] = make_float4(a.ox[0], a.oy[0], a.oz[0], __int_as_float(0));
+    int j = 0;  // the reference's literal seed
+    if (a.spix) {  // the target point of the query's own pixel, else of the nearest occupied pixel of the 5 x 5 around it
+      const int p = a.spix[i];
+      const int r = p / a.cols, c = p - r * a.cols;
+      int found = a.tidx[p];
+      for (int ring = 1; ring <= 2 && found < 0; ++ring) {
+        int best_d = 1 << 30;
+        for (int dr = -ring; dr <= ring; ++dr) {
+          const int rr = r + dr;
+          if (rr < 0 || rr >= a.rows) continue;
+          for (int dc = -ring; dc <= ring; ++dc) {
+            if ((dr > -ring && dr < ring) && (dc > -ring && dc < ring)) continue;  // (the inner rings have been looked at)
+            const int cc = c + dc;
+            if (cc < 0 || cc >= a.cols) continue;
+            const int t = a.tidx[rr * a.cols + cc];
+            const int d2 = dr * dr + dc * dc;
+            if (t >= 0 && d2 < best_d) {
+              best_d = d2;
+              found = t;
+            }
+          }
+        }
+      }
+      if (found >= 0) j = found;
+    }
+    a.sp[ip] = make_float4(a.ox[j], a.oy[j], a.oz[j], __int_as_float(j));
     a.seed_m[ip] = 0ull;
   }
 }
@@ -407,7 +432,7 @@ void launch_grid_qscatter(const int* qcell, const int* qslot, const int* qstart,
                           const float* qy, const float* qz, const float* ox, const float* oy, const float* oz,
                           float4* qm4, float4* sp, nn_key_t* seed_m, hipStream_t s) {
   if (n <= 0) return;
-  const QscatterArgs a{qcell, qslot, qstart, qperm, qx, qy, qz, ox, oy, oz, qm4, sp, seed_m, n, 0};
+  const QscatterArgs a{qcell, qslot, qstart, qperm, qx, qy, qz, ox, oy, oz, qm4, sp, seed_m, n, 0, nullptr, nullptr, 0, 0};
   ICPK_RECORD(SK_QSCATTER, qscatter, a)
   hipLaunchKernelGGL(grid_qscatter_kernel, dim3((n + 255) / 256), dim3(256), 0, s, a);
 }

@@ -307,6 +307,47 @@ def test_align_after_backproject_pair_skips_the_source_copy_only_when_it_may(mon
         assert g == w, k
 
 
+@pytest.mark.parametrize("env", [{"ICPK_PIXEL_SEEDS": "0"}, {"ICPK_ZERO_COPY_UPLOAD": "0"}, {"ICPK_RESULT_MIRROR": "0"},
+                                 {"ICPK_PIXEL_SEEDS": "0", "ICPK_ZERO_COPY_UPLOAD": "0", "ICPK_RESULT_MIRROR": "0", "ICPK_PRISTINE_SKIP": "0"}])
+@pytest.mark.parametrize("filt", [False, True])
+def test_frame_path_shortcuts_do_not_change_results(env, filt, monkeypatch):
+    """Image-space seeds for the first sweep, the zero-copy upload, the outputs through mapped host memory and the
+    skipped source copy are ways of getting the same numbers sooner: clouds, transforms, iteration counts, traces and
+    aligned sources of a frame sequence equal those of a context with the shortcuts switched off (read at creation)."""
+    rows, cols = 120, 160
+    fx, cx = float(synth.FX) * cols / 640, float(synth.CX) * cols / 640
+    rng = np.random.default_rng(21)
+    frames = []
+    for k in range(5):
+        d = synth.render_room_depth(rows, cols, synth.rot_xyz_deg(0, 0.6 * k, 0.1 * k), np.array([0.01 * k, 0, 0.004 * k]),
+                                    fx, cx, noise_sigma=0.002, rng=rng)
+        d[rng.random(d.shape) > (0.3 if k % 2 else 0.8)] = 0  # sparse and dense frames: seeds from neighbouring pixels, and none at all
+        frames.append(d.astype(np.uint16))
+    frames[3][:, : cols // 2] = 0  # half of a frame empty: queries whose 5 x 5 neighbourhood holds no target
+
+    def run():
+        out = []
+        with binding.Context(0) as c:
+            for k in range(1, len(frames)):
+                R = binding.make_rotation_matrix(0.2 * k, -0.1 * k, 0.05)
+                t = np.array([5 + 0.01 * k, 5, 5], np.float32)
+                n = c.backproject_pair(frames[k], frames[k - 1] if k in (1, 3) else None, R=R, t=t, fx=fx, cx=cx, filter=filt)
+                src, tgt = c.get_source().tobytes(), c.get_target().tobytes()
+                T, st, rc = c.align(max_iterations=12, threshold=1e-5)
+                tr = c.get_trace(12)
+                out.append((n, src, tgt, T.tobytes(), st.iterations, st.final_pairs, rc, c.get_source().tobytes(),
+                            tuple((e["R"].tobytes(), e["t"].tobytes(), e["n_pairs"], e["mse"].tobytes()) for e in tr)))
+        return out
+
+    want = run()
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    got = run()
+    assert len(got) == len(want) == 4
+    for k, (g, w) in enumerate(zip(got, want)):
+        assert g == w, k
+
+
 def test_backproject_pair_empty_frames_and_bad_arguments():
     z = np.zeros((24, 40), np.uint16)
     d = z.copy()
