@@ -86,6 +86,7 @@ struct icpk_ctx {
   int* pix_src = nullptr;              // ... and the pixel of every source point: image-space seeds of the alignment that follows
   int pix_cap = 0;
   bool have_pix_seed = false;          // they describe the clouds the context holds now
+  bool image_order = true;             // ICPK_IMAGE_ORDER=0: sort the queries of an image-ordered source by cell like any other (diagnostic)
   bool pixel_seeds = true;             // ICPK_PIXEL_SEEDS=0: the reference's literal seed (diagnostic)
   int pix_rows = 0, pix_cols = 0;
   bool src_pristine = false;     // the working source equals the committed one (see copy_src0_to_src)

@@ -202,7 +202,7 @@ __global__ void grid_qslot_batch_kernel(const SetupBatchOf<QslotArgs> b) { grid_
 __device__ __forceinline__ void grid_qscatter_body(const QscatterArgs& a, const int block) {
   const int i = block * blockDim.x + threadIdx.x;
   if (i >= a.n) return;
-  const int ip = a.qstart[a.qcell[i]] + a.qslot[i];
+  const int ip = a.qcell ? a.qstart[a.qcell[i]] + a.qslot[i] : i;  // (qcell == nullptr: the caller's order is the scan order)
   a.qperm[ip] = i;
   if (a.qm4) {
     a.qm4[ip] = make_float4(a.qx[i], a.qy[i], a.qz[i], __int_as_float(i));
@@ -211,24 +211,29 @@ __device__ __forceinline__ void grid_qscatter_body(const QscatterArgs& a, const 
       const int p = a.spix[i];
       const int r = p / a.cols, c = p - r * a.cols;
       int found = a.tidx[p];
-      for (int ring = 1; ring <= 2 && found < 0; ++ring) {
-        int best_d = 1 << 30;
-        for (int dr = -ring; dr <= ring; ++dr) {
-          const int rr = r + dr;
-          if (rr < 0 || rr >= a.rows) continue;
-          for (int dc = -ring; dc <= ring; ++dc) {
-            if ((dr > -ring && dr < ring) && (dc > -ring && dc < ring)) continue;  // (the inner rings have been looked at)
-            const int cc = c + dc;
-            if (cc < 0 || cc >= a.cols) continue;
-            const int t = a.tidx[rr * a.cols + cc];
+      // (a ring's pixels are read together -- clamped addresses, no branch around a load -- and the nearest occupied one wins)
+      auto ring_search = [&](auto ring_c) {
+        constexpr int RING = decltype(ring_c)::value;
+        int best = -1, best_d = 1 << 30;
+#pragma unroll
+        for (int dr = -RING; dr <= RING; ++dr) {
+#pragma unroll
+          for (int dc = -RING; dc <= RING; ++dc) {
+            if ((dr > -RING && dr < RING) && (dc > -RING && dc < RING)) continue;  // (the inner rings have been looked at)
+            const int rr = r + dr, cc = c + dc;
+            const bool inside = rr >= 0 && rr < a.rows && cc >= 0 && cc < a.cols;
+            const int t = a.tidx[min(max(rr, 0), a.rows - 1) * a.cols + min(max(cc, 0), a.cols - 1)];
             const int d2 = dr * dr + dc * dc;
-            if (t >= 0 && d2 < best_d) {
+            if (inside && t >= 0 && d2 < best_d) {
               best_d = d2;
-              found = t;
+              best = t;
             }
           }
         }
-      }
+        return best;
+      };
+      if (found < 0) found = ring_search(std::integral_constant<int, 1>{});
+      if (found < 0) found = ring_search(std::integral_constant<int, 2>{});
       if (found >= 0) j = found;
     }
     a.sp[ip] = make_float4(a.ox[j], a.oy[j], a.oz[j], __int_as_float(j));

@@ -307,8 +307,9 @@ def test_align_after_backproject_pair_skips_the_source_copy_only_when_it_may(mon
         assert g == w, k
 
 
-@pytest.mark.parametrize("env", [{"ICPK_PIXEL_SEEDS": "0"}, {"ICPK_ZERO_COPY_UPLOAD": "0"}, {"ICPK_RESULT_MIRROR": "0"},
-                                 {"ICPK_PIXEL_SEEDS": "0", "ICPK_ZERO_COPY_UPLOAD": "0", "ICPK_RESULT_MIRROR": "0", "ICPK_PRISTINE_SKIP": "0"}])
+@pytest.mark.parametrize("env", [{"ICPK_PIXEL_SEEDS": "0"}, {"ICPK_ZERO_COPY_UPLOAD": "0"}, {"ICPK_RESULT_MIRROR": "0"}, {"ICPK_IMAGE_ORDER": "0"},
+                                 {"ICPK_PIXEL_SEEDS": "0", "ICPK_ZERO_COPY_UPLOAD": "0", "ICPK_RESULT_MIRROR": "0", "ICPK_PRISTINE_SKIP": "0",
+                                  "ICPK_IMAGE_ORDER": "0"}])
 @pytest.mark.parametrize("filt", [False, True])
 def test_frame_path_shortcuts_do_not_change_results(env, filt, monkeypatch):
     """Image-space seeds for the first sweep, the zero-copy upload, the outputs through mapped host memory and the
