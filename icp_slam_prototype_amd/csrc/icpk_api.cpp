@@ -1384,7 +1384,10 @@ static int align_device_loop(icpk_ctx* ctx, const icpk_params* p, float T_out[16
   ICPK_HIP(ctx, hipGetLastError());
   const LoopState* result = nullptr;
   if (mirror) {
-    if (throttled) {  // (what is still enqueued -- a no-op sweep, the unpack -- is stream-ordered before whatever comes next)
+    // a loop enqueued whole is waited for the same way when it is short (well under a millisecond of device time: the
+    // host would otherwise sleep through the unpack and its own wake-up); long ones leave the core alone
+    const bool brief = (long long)ctx->src.n * p->max_iterations <= 8000000ll;
+    if (throttled || brief) {  // (what is still enqueued -- a no-op sweep, the unpack -- is stream-ordered before whatever comes next)
       bool ready = false;
       rc = wait_loop_progress(ctx, -1, &ready);
       if (rc) return rc;
