@@ -2229,6 +2229,20 @@ static int check_filter(icpk_ctx* ctx, int morph, int& ax, int& ay) {
 }
 
 // raw + filtered depth images on the device (`count` pixels each) and `ints` block-count words
+// the subsample key of the next image this context back-projects (kernels_backproject.hip: bp_keep)
+static unsigned long long next_subsample_key(icpk_ctx* ctx) {
+  const unsigned long long k = ctx->sub_stream++;
+  return ctx->sub_seed + (k + 1ull) * 0x9E3779B97F4A7C15ull;
+}
+
+int icpk_set_subsample(icpk_ctx* ctx, int32_t factor, uint64_t seed) {
+  if (!ctx || factor < 0) return ICPK_E_ARG;
+  ctx->sub_factor = factor;
+  ctx->sub_seed = seed;
+  ctx->sub_stream = 0;
+  return ICPK_OK;
+}
+
 static int ensure_depth_buffers(icpk_ctx* ctx, int count, int ints) {
   if (count > ctx->depth_cap) {
     if (ctx->depth_dev) ICPK_HIP(ctx, hipFree(ctx->depth_dev));
@@ -2283,7 +2297,8 @@ static int backproject_impl(icpk_ctx* ctx, const uint16_t* depth, int32_t rows, 
     nzp = ctx->nrm.z();
   }
   launch_backproject(dimg, rows, cols, fx, cx, ox, oy, oz, c.x(), c.y(), c.z(), nxp, nyp, nzp,
-                     normals_mode < 0 ? 0 : normals_mode, ctx->bp_counts, ctx->bp_counts + nblocks + 1, ctx->stream);
+                     normals_mode < 0 ? 0 : normals_mode, ctx->bp_counts, ctx->bp_counts + nblocks + 1, next_subsample_key(ctx),
+                     ctx->sub_factor, ctx->stream);
   ICPK_HIP(ctx, hipGetLastError());
   ICPK_HIP(ctx, hipMemcpyAsync(ctx->bp_n_host, ctx->bp_counts + nblocks + 1, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   ICPK_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -2399,10 +2414,14 @@ int icpk_backproject_pair(icpk_ctx* ctx, const uint16_t* depth_source, const uin
   const uint16_t* stage_dev = nullptr;
   if (zero_copy) ICPK_HIP(ctx, hipHostGetDevicePointer((void**)&stage_dev, ctx->stage_depth, 0));
   b.im[0] = BpImage{img_s, ctx->src0.x(), ctx->src0.y(), ctx->src0.z(), ctx->src.x(), ctx->src.y(), ctx->src.z(),
-                    ctx->bp_counts, 0.f, ctx->pix_src, nullptr, zero_copy ? stage_dev : nullptr, raw_s};
+                    ctx->bp_counts, 0.f, ctx->pix_src, nullptr, zero_copy ? stage_dev : nullptr, raw_s, 0, 0, 0};
   b.im[1] = BpImage{img_t, ctx->tgt.x(), ctx->tgt.y(), ctx->tgt.z(), nullptr, nullptr, nullptr,
                     ctx->bp_counts + per_image, __builtin_inff(), nullptr, ctx->pix_tidx,
-                    zero_copy && !resident ? stage_dev + npix : nullptr, raw_t};
+                    zero_copy && !resident ? stage_dev + npix : nullptr, raw_t, 0, 0, 0};
+  // (icp.cpp:38-39 builds the cloud of `data` first, then that of `previous`: the source draws its pattern first)
+  b.im[0].sub_key = next_subsample_key(ctx);
+  b.im[1].sub_key = next_subsample_key(ctx);
+  b.im[0].sub_factor = b.im[1].sub_factor = ctx->sub_factor;
   Rt rt{};
   if (R) {
     std::memcpy(rt.R, R, sizeof(rt.R));

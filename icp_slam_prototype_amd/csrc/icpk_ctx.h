@@ -79,6 +79,9 @@ struct icpk_ctx {
   icpk::LoopInitArgs pending_init{};         // device_loop_begin(defer): the initial LoopState not launched yet
   bool init_pending = false;
   int* grid_ticket = nullptr;          // grid_begin_kernel's arrival counter (zero between launches)
+  int sub_factor = 0;                  // icpk_set_subsample: keep one valid pixel in sub_factor (<= 1: all), chosen by ...
+  unsigned long long sub_seed = 0;     // ... a hash of this seed, the image's stream number and the pixel
+  unsigned long long sub_stream = 0;   // images back-projected since icpk_set_subsample (every image draws a fresh pattern, as rand() would)
   bool zero_copy_upload = true;        // ICPK_ZERO_COPY_UPLOAD=0: copy-engine transfer from the staging buffer instead (diagnostic)
   uint16_t* stage_depth = nullptr;     // pinned: icpk_backproject_pair's images on their way to the device
   int stage_depth_cap = 0;

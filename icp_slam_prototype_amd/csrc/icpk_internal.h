@@ -276,7 +276,7 @@ void launch_ingest_cloud(const float* x, const float* y, const float* z, int n, 
 // nx == nullptr: no normals
 void launch_backproject(const uint16_t* depth, int rows, int cols, float fx, float cx, float ox, float oy, float oz,
                         float* x, float* y, float* z, float* nx, float* ny, float* nz, int normals_mode,
-                        int* block_counts, int* n_out, hipStream_t s);
+                        int* block_counts, int* n_out, unsigned long long sub_key, int sub_factor, hipStream_t s);
 // icpk_backproject_pair: image 0 = current frame (source; x2/y2/z2 = its working copy), image 1 = previous
 // frame (target).  counts: nblocks + 2 ints per image.
 struct BpImage {
@@ -294,6 +294,8 @@ struct BpImage {
   // which `depth` points to for the scatter pass
   const uint16_t* host_src;
   uint16_t* raw_out;
+  unsigned long long sub_key;  // seeded subsample of this image (kernels_backproject.hip: bp_keep); factor <= 1: none
+  int sub_factor, pad1;
 };
 struct BpPair {
   BpImage im[2];

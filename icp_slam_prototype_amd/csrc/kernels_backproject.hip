@@ -3,7 +3,7 @@
 // pointcloud.cpp:19-58: row-major scan, zero depth skipped,
 //   p_z = (float)d / 5000.0f; p_x = (x - CX) * p_z / FX; p_y = (y - CX) * p_z / FX
 // (CX and FX are used for the y axis too, pointcloud.cpp:39).  The unseeded
-// rand()%40 subsample of pointcloud.cpp:28 is not reproduced.  Output order is
+// rand()%40 subsample of pointcloud.cpp:28 has a seeded stand-in (bp_keep below; off by default).  Output order is
 // the row-major order of the valid pixels (order-preserving compaction):
 //   pass 1: per-1024-pixel block count (wave64 ballot + popcount)
 //   pass 2: exclusive scan of the block counts (one workgroup)
@@ -12,6 +12,20 @@
 
 namespace icpk {
 
+// The reference keeps one valid pixel in SUBSAMPLE_FACTOR at random (pointcloud.cpp:27-30, `rand() % 40`, never
+// seeded).  Here, when a factor > 1 is set (icpk_set_subsample): a counter-based choice -- pixel p of image stream k
+// is kept iff the upper half of splitmix64(seed + (k + 1) * golden + p * odd) is a multiple of the factor -- the same
+// for the counting and the scatter pass, reproducible, restated in oracle/icp_oracle.py:subsample_keep.
+// key = seed + (k + 1) * 0x9E3779B97F4A7C15 is formed on the host; factor <= 1: every valid pixel.
+__host__ __device__ __forceinline__ bool bp_keep(unsigned long long key, int factor, int p) {
+  if (factor <= 1) return true;
+  unsigned long long z = key + (unsigned long long)(unsigned)p * 0xD1B54A32D192ED03ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return (unsigned)(z >> 32) % (unsigned)factor == 0u;
+}
+
 constexpr int BP_THREADS = 256;
 constexpr int BP_PER_THREAD = 4;
 constexpr int BP_BLOCK = BP_THREADS * BP_PER_THREAD;  // 1024 pixels per workgroup
@@ -19,7 +33,8 @@ constexpr int BP_BLOCK = BP_THREADS * BP_PER_THREAD;  // 1024 pixels per workgro
 __device__ __forceinline__ void bp_count_body(const uint16_t* __restrict__ depth, int npix,
                                               int* __restrict__ block_counts, const int block,
                                               const uint16_t* __restrict__ host_src = nullptr,
-                                              uint16_t* __restrict__ raw_out = nullptr) {
+                                              uint16_t* __restrict__ raw_out = nullptr, unsigned long long sub_key = 0,
+                                              int sub_factor = 0) {
   const int base = block * BP_BLOCK;
   int c = 0;
   if (host_src) {  // (all four loads in flight before the first is looked at: they cross PCIe)
@@ -33,13 +48,13 @@ __device__ __forceinline__ void bp_count_body(const uint16_t* __restrict__ depth
     for (int k = 0; k < BP_PER_THREAD; ++k) {
       const int p = base + k * BP_THREADS + threadIdx.x;
       if (p < npix) raw_out[p] = d[k];
-      c += __popcll(__ballot(d[k] != 0));
+      c += __popcll(__ballot(d[k] != 0 && bp_keep(sub_key, sub_factor, p)));
     }
   } else {
 #pragma unroll
     for (int k = 0; k < BP_PER_THREAD; ++k) {
       const int p = base + k * BP_THREADS + threadIdx.x;
-      const bool valid = p < npix && depth[p] != 0;
+      const bool valid = p < npix && depth[p] != 0 && bp_keep(sub_key, sub_factor, p);
       c += __popcll(__ballot(valid));
     }
   }
@@ -50,14 +65,15 @@ __device__ __forceinline__ void bp_count_body(const uint16_t* __restrict__ depth
 }
 
 __global__ __launch_bounds__(BP_THREADS) void bp_count_kernel(const uint16_t* __restrict__ depth, int npix,
-                                                              int* __restrict__ block_counts) {
-  bp_count_body(depth, npix, block_counts, blockIdx.x);
+                                                              int* __restrict__ block_counts, unsigned long long sub_key,
+                                                              int sub_factor) {
+  bp_count_body(depth, npix, block_counts, blockIdx.x, nullptr, nullptr, sub_key, sub_factor);
 }
 
 // frame-pair entry (icpk_backproject_pair): blockIdx.y = image (0: current frame / source, 1: previous / target)
 __global__ __launch_bounds__(BP_THREADS) void bp_count_pair_kernel(const BpPair b, int npix) {
   const BpImage& im = b.im[blockIdx.y];
-  bp_count_body(im.depth, npix, im.counts, blockIdx.x, im.host_src, im.raw_out);
+  bp_count_body(im.depth, npix, im.counts, blockIdx.x, im.host_src, im.raw_out, im.sub_key, im.sub_factor);
 }
 
 // exclusive scan in place; block_counts[nblocks] receives the total
@@ -152,7 +168,8 @@ __global__ __launch_bounds__(BP_THREADS) void bp_scatter_kernel(const uint16_t* 
                                                                 float* __restrict__ x, float* __restrict__ y,
                                                                 float* __restrict__ z, float* __restrict__ nxp,
                                                                 float* __restrict__ nyp, float* __restrict__ nzp,
-                                                                int normals_mode) {
+                                                                int normals_mode, unsigned long long sub_key,
+                                                                int sub_factor) {
   __shared__ int wcount[BP_PER_THREAD][BP_THREADS / 64];
   const int base = blockIdx.x * BP_BLOCK;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -162,6 +179,7 @@ __global__ __launch_bounds__(BP_THREADS) void bp_scatter_kernel(const uint16_t* 
   for (int k = 0; k < BP_PER_THREAD; ++k) {
     const int p = base + k * BP_THREADS + threadIdx.x;
     dv[k] = p < npix ? depth[p] : (uint16_t)0;
+    if (!bp_keep(sub_key, sub_factor, p)) dv[k] = 0;  // (a pixel the subsample drops is an empty pixel from here on)
     mask[k] = __ballot(dv[k] != 0);
     if (lane == 0) wcount[k][wave] = __popcll(mask[k]);
   }
@@ -219,6 +237,7 @@ __global__ __launch_bounds__(BP_THREADS) void bp_scatter_pair_kernel(const BpPai
   for (int k = 0; k < BP_PER_THREAD; ++k) {
     const int p = base + k * BP_THREADS + threadIdx.x;
     dv[k] = p < npix ? depth[p] : (uint16_t)0;
+    if (!bp_keep(im.sub_key, im.sub_factor, p)) dv[k] = 0;
     mask[k] = __ballot(dv[k] != 0);
     if (lane == 0) wcount[k][wave] = __popcll(mask[k]);
   }
@@ -280,17 +299,17 @@ void launch_backproject_pair(const BpPair& b, int rows, int cols, float fx, floa
 
 void launch_backproject(const uint16_t* depth, int rows, int cols, float fx, float cx, float ox, float oy, float oz,
                         float* x, float* y, float* z, float* nx, float* ny, float* nz, int normals_mode,
-                        int* block_counts, int* n_out, hipStream_t s) {
+                        int* block_counts, int* n_out, unsigned long long sub_key, int sub_factor, hipStream_t s) {
   const int npix = rows * cols;
   const int nblocks = (npix + BP_BLOCK - 1) / BP_BLOCK;
-  hipLaunchKernelGGL(bp_count_kernel, dim3(nblocks), dim3(BP_THREADS), 0, s, depth, npix, block_counts);
+  hipLaunchKernelGGL(bp_count_kernel, dim3(nblocks), dim3(BP_THREADS), 0, s, depth, npix, block_counts, sub_key, sub_factor);
   hipLaunchKernelGGL(bp_scan_kernel, dim3(1), dim3(256), 0, s, block_counts, nblocks, n_out);
   if (nx)
     hipLaunchKernelGGL(bp_scatter_kernel<true>, dim3(nblocks), dim3(BP_THREADS), 0, s, depth, npix, cols, fx, cx, ox, oy,
-                       oz, block_counts, x, y, z, nx, ny, nz, normals_mode);
+                       oz, block_counts, x, y, z, nx, ny, nz, normals_mode, sub_key, sub_factor);
   else
     hipLaunchKernelGGL(bp_scatter_kernel<false>, dim3(nblocks), dim3(BP_THREADS), 0, s, depth, npix, cols, fx, cx, ox,
-                       oy, oz, block_counts, x, y, z, nx, ny, nz, normals_mode);
+                       oy, oz, block_counts, x, y, z, nx, ny, nz, normals_mode, sub_key, sub_factor);
 }
 
 }  // namespace icpk

@@ -63,6 +63,9 @@ class Engine {
   Engine& operator=(const Engine&) = delete;
   icpk_ctx* ctx() const { return ctx_; }
   const char* last_error() const { return icpk_last_error(ctx_); }
+  // pointcloud.cpp:27-30 (SUBSAMPLE_FACTOR, pointcloud.hpp:11) with a reproducible choice instead of rand(): every
+  // cloud this engine back-projects from now on keeps one valid pixel in `factor` (0 / 1: all of them)
+  int setSubsample(int factor = ICPK_SUBSAMPLE_FACTOR, uint64_t seed = 0) { return icpk_set_subsample(ctx_, factor, seed); }
 
  private:
   icpk_ctx* ctx_ = nullptr;

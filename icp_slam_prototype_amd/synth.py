@@ -4,7 +4,7 @@ Pure numpy; used by bench.py and tests/.  No dataset ships with the reference
 (CoRBS/TUM sequences are not fetchable), so every workload is generated:
 depth images are ray-cast from a small analytic room and back-projected with
 the reference's own formula (pointcloud.cpp:37-39, including its use of CX/FX
-for the y axis) WITHOUT the rand()%40 subsample (pointcloud.cpp:28).
+for the y axis) WITHOUT the rand()%40 subsample (pointcloud.cpp:28; the library's seeded stand-in is icpk_set_subsample).
 """
 import numpy as np
 

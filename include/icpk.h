@@ -285,7 +285,19 @@ int icpk_comm_barrier(icpk_ctx *ctx);
 int icpk_align_query_sharded(icpk_ctx *ctx, const icpk_params *p, float T_out[16], icpk_stats *stats);
 
 /* ---- front end -------------------------------------- */
-/* pointcloud.cpp:19-58 without the rand()%40 subsample: row-major back-
+/* pointcloud.cpp:27-30: the reference keeps one valid pixel in SUBSAMPLE_FACTOR, chosen by an unseeded rand().
+ * factor > 1: every back-projection of this context (icpk_backproject*, both images of icpk_backproject_pair --
+ * the source first, then the target, as icp.cpp:38-39 builds them; a resident previous frame draws a fresh
+ * pattern too, as the reference's rebuilt cloud does) keeps a valid pixel p iff
+ *   z = seed + (k + 1) * 0x9E3779B97F4A7C15 + p * 0xD1B54A32D192ED03          (k = images since this call, mod 2^64)
+ *   z = (z ^ z >> 30) * 0xBF58476D1CE4E5B9;  z = (z ^ z >> 27) * 0x94D049BB133111EB;  z ^= z >> 31
+ *   (uint32)(z >> 32) % factor == 0
+ * -- reproducible, unlike rand(); the stream of the reference's C library is not pinned by anything it ships.
+ * factor 0 or 1 (the default): every valid pixel.  Resets k to 0. */
+#define ICPK_SUBSAMPLE_FACTOR 40 /* pointcloud.hpp:11 */
+int icpk_set_subsample(icpk_ctx *ctx, int32_t factor, uint64_t seed);
+
+/* pointcloud.cpp:19-58 (the subsample of :27-30 as set by icpk_set_subsample; none by default): row-major back-
  * projection of a rows x cols uint16 depth image (host pointer) into the
  * source (which = 0) or target (which = 1) cloud, adding `offset` to every
  * coordinate afterwards (PointCloud::translate(cameraPosition), icp.cpp:71).

@@ -254,6 +254,21 @@ def to_euler(q):
     return e
 
 
+def subsample_keep(rows, cols, factor, seed, stream):
+    """The seeded stand-in for pointcloud.cpp:27-30 (`rand() % SUBSAMPLE_FACTOR`) as include/icpk.h defines it for
+    icpk_set_subsample: uint8 mask over the rows x cols pixels of image number `stream` (0-based count of the images
+    back-projected since the subsample was set).  Pass it as `keep` to backproject."""
+    if factor <= 1:
+        return np.ones((rows, cols), np.uint8)
+    with np.errstate(over="ignore"):
+        p = np.arange(rows * cols, dtype=np.uint64)
+        z = np.uint64(seed) + np.uint64(stream + 1) * np.uint64(0x9E3779B97F4A7C15) + p * np.uint64(0xD1B54A32D192ED03)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return (((z >> np.uint64(32)).astype(np.uint32) % np.uint32(factor)) == 0).astype(np.uint8).reshape(rows, cols)
+
+
 def backproject(depth, keep=None, fx=468.60, cx=318.27):
     depth = np.ascontiguousarray(depth, np.uint16)
     rows, cols = depth.shape

@@ -349,6 +349,72 @@ def test_frame_path_shortcuts_do_not_change_results(env, filt, monkeypatch):
         assert g == w, k
 
 
+def test_seeded_subsample_matches_the_oracle(oracle):
+    """pointcloud.cpp:27-30 keeps one valid pixel in SUBSAMPLE_FACTOR by an unseeded rand(); icpk_set_subsample makes the
+    same cut with a counter-based hash (include/icpk.h).  Every back-projecting entry point against the oracle's
+    back-projection under oracle.subsample_keep's mask, bit for bit, image stream by image stream (each image draws a
+    fresh pattern -- the resident previous frame too); factor 0 / 1 switch it off; a pair made with it aligns as the
+    same clouds set by hand do."""
+    rows, cols = 120, 160
+    fx, cx = float(synth.FX) * cols / 640, float(synth.CX) * cols / 640
+    rng = np.random.default_rng(31)
+    frames = []
+    for k in range(4):
+        d = synth.render_room_depth(rows, cols, synth.rot_xyz_deg(0, 0.5 * k, 0), np.array([0.01 * k, 0, 0]), fx, cx,
+                                    noise_sigma=0.002, rng=rng)
+        d[rng.random(d.shape) > 0.8] = 0
+        d[::9, ::7] = 30000  # (outside the filter's range)
+        frames.append(d.astype(np.uint16))
+    factor, seed = 4, 2 ** 63 + 12345
+    keep = lambda stream: oracle.subsample_keep(rows, cols, factor, seed, stream)
+    cloud = lambda d, stream: oracle.backproject(d, keep=keep(stream), fx=fx, cx=cx)
+    R = binding.make_rotation_matrix(3.0, -2.0, 1.0)
+    t = np.array([5.0, 5.1, 4.9], np.float32)
+    with binding.Context(0) as c:
+        with pytest.raises(binding.IcpkError):
+            c.set_subsample(-1, 0)
+        c.set_subsample(factor, seed)
+        n = c.backproject(frames[0], which=1, fx=fx, cx=cx)  # stream 0
+        want = cloud(frames[0], 0)
+        assert n == want.shape[1] and 0.15 * (frames[0] != 0).sum() < n < 0.35 * (frames[0] != 0).sum()
+        assert c.get_target().tobytes() == want.tobytes()
+        c.backproject(frames[1], which=0, fx=fx, cx=cx)  # stream 1: another pattern
+        assert c.get_source().tobytes() == cloud(frames[1], 1).tobytes()
+        assert not np.array_equal(keep(0), keep(1))
+        c.backproject_filtered(frames[2], which=1, fx=fx, cx=cx)  # stream 2: the filter first, then the cut
+        assert c.get_target().tobytes() == cloud(oracle.filter_depth_image(frames[2]), 2).tobytes()
+        c.backproject_with_normals(frames[0], binding.NORMALS_CROSS, fx=fx, cx=cx)  # stream 3: normals of the FULL image's neighbours
+        pts, nrm = oracle.backproject_normals(frames[0], mode=0, fx=fx, cx=cx)
+        sel = keep(3).reshape(-1)[np.flatnonzero(frames[0].reshape(-1))] != 0
+        assert c.get_target().tobytes() == np.ascontiguousarray(pts[:, sel]).tobytes()
+        assert c.get_target_normals().tobytes() == np.ascontiguousarray(nrm[:, sel]).tobytes()
+        # the pair call: source = stream 4, target = stream 5; with the previous frame resident: 6 and 7
+        ns, nt = c.backproject_pair(frames[2], frames[1], R=R, t=t, fx=fx, cx=cx)
+        src = oracle.transform_points(cloud(frames[2], 4), R, t)
+        tgt = oracle.transform_points(cloud(frames[1], 5), R, t)
+        assert (ns, nt) == (src.shape[1], tgt.shape[1])
+        assert c.get_source().tobytes() == src.tobytes() and c.get_target().tobytes() == tgt.tobytes()
+        c.backproject_pair(frames[3], None, R=R, t=t, fx=fx, cx=cx)
+        src = oracle.transform_points(cloud(frames[3], 6), R, t)
+        tgt = oracle.transform_points(cloud(frames[2], 7), R, t)
+        assert c.get_source().tobytes() == src.tobytes() and c.get_target().tobytes() == tgt.tobytes()
+        T1, s1, r1 = c.align(max_iterations=10, threshold=1e-5)  # (image-space seeds over a thinned image: most pixels hold no point)
+        with binding.Context(0) as d:
+            d.set_target(tgt)
+            d.set_source(src)
+            T2, s2, r2 = d.align(max_iterations=10, threshold=1e-5)
+        assert np.array_equal(T1, T2) and (s1.iterations, s1.final_pairs, r1) == (s2.iterations, s2.final_pairs, r2)
+        # the reference's factor, and off again
+        c.set_subsample(binding.SUBSAMPLE_FACTOR, 1)
+        n40 = c.backproject(frames[0], which=1, fx=fx, cx=cx)
+        assert c.get_target().tobytes() == oracle.backproject(frames[0], keep=oracle.subsample_keep(rows, cols, 40, 1, 0), fx=fx, cx=cx).tobytes()
+        assert 0 < n40 < (frames[0] != 0).sum() / 20
+        for off in (1, 0):
+            c.set_subsample(off, 99)
+            assert c.backproject(frames[0], which=1, fx=fx, cx=cx) == int((frames[0] != 0).sum())
+            assert c.get_target().tobytes() == oracle.backproject(frames[0], fx=fx, cx=cx).tobytes()
+
+
 def test_backproject_pair_empty_frames_and_bad_arguments():
     z = np.zeros((24, 40), np.uint16)
     d = z.copy()

@@ -495,3 +495,28 @@ def test_oracle_regression_fixture(oracle):
     assert np.array_equal(oracle.make_rotation_matrix(10, 20, 30), g["f5_rot_10_20_30"])
     assert np.array_equal(oracle.quaternion_from_matrix(g["f5_rot_10_20_30"]), g["f5_quat"])
     assert np.array_equal(oracle.to_euler(g["f5_quat"]), g["f5_euler"])
+
+
+def test_subsample_keep_follows_the_formula_in_icpk_h(oracle):
+    """oracle.subsample_keep (numpy, wrapping uint64) against the formula of include/icpk.h written out with Python
+    integers; known answers for one small image; about one pixel in `factor` is kept and streams differ."""
+    M = (1 << 64) - 1
+
+    def keep(seed, stream, p, factor):
+        z = (seed + (stream + 1) * 0x9E3779B97F4A7C15 + p * 0xD1B54A32D192ED03) & M
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M
+        z ^= z >> 31
+        return int((z >> 32) % factor == 0)
+
+    for seed, stream, factor in ((5, 0, 3), (2 ** 64 - 1, 7, 40), (2 ** 63 + 12345, 4, 4), (0, 1000, 2)):
+        got = oracle.subsample_keep(6, 50, factor, seed, stream).reshape(-1)
+        assert got.tolist() == [keep(seed, stream, p, factor) for p in range(300)]
+    assert oracle.subsample_keep(2, 16, 3, 5, 0).tolist() == [[0, 0, 0, 1, 0, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0],
+                                                             [1, 1, 0, 0, 1, 1, 0, 1, 0, 1, 0, 0, 0, 1, 0, 0]]
+    a, b = oracle.subsample_keep(480, 640, 40, 0, 0), oracle.subsample_keep(480, 640, 40, 0, 1)
+    assert int(a.sum()) == 7738 and abs(int(b.sum()) - 7680) < 300 and not np.array_equal(a, b)
+    assert oracle.subsample_keep(3, 4, 1, 9, 0).all() and oracle.subsample_keep(3, 4, 0, 9, 0).all()
+    d = np.arange(1, 13, dtype=np.uint16).reshape(3, 4)
+    m = oracle.subsample_keep(3, 4, 2, 9, 0)
+    assert oracle.backproject(d, keep=m).shape[1] == int(m.sum())
