@@ -36,7 +36,7 @@ SYMBOLS = [
     "icpk_align_batch", "icpk_align_batch_device", "icpk_backproject", "icpk_backproject_with_normals", "icpk_set_target_normals",
     "icpk_get_target_normals", "icpk_reduce_p2l", "icpk_solve_point_to_plane", "icpk_pair_distance", "icpk_pair_distance3", "icpk_distance3", "icpk_make_rotation_matrix",
     "icpk_matrix_to_quaternion", "icpk_quaternion_to_euler", "icpk_solve_reference", "icpk_solve_kabsch",
-    "icpk_associate_keypoints", "icpk_filter_depth_image", "icpk_backproject_filtered", "icpk_backproject_pair", "icpk_set_subsample",
+    "icpk_associate_keypoints", "icpk_filter_depth_image", "icpk_backproject_filtered", "icpk_backproject_pair", "icpk_set_subsample", "icpk_backproject_keypoints",
     "icpk_comm_unique_id", "icpk_comm_init_rccl", "icpk_comm_destroy", "icpk_comm_rank", "icpk_comm_world",
     "icpk_comm_partition", "icpk_comm_broadcast_target", "icpk_comm_gather_results", "icpk_comm_allreduce_sums",
     "icpk_comm_barrier", "icpk_align_query_sharded",
@@ -150,6 +150,8 @@ def load():
     lib.icpk_default_params.restype = None
     lib.icpk_set_log_callback.argtypes = [C.c_void_p, LOG_FN, C.c_void_p]
     lib.icpk_make_rotation_matrix.argtypes = [C.c_float, C.c_float, C.c_float, fp]
+    lib.icpk_backproject_keypoints.argtypes = [C.POINTER(C.c_uint16), C.c_int32, C.c_int32, fp, C.c_int32, C.c_float, C.c_float, fp,
+                                               C.POINTER(C.c_int32)]
     lib.icpk_make_rotation_matrix.restype = None
     lib.icpk_matrix_to_quaternion.argtypes = [fp, fp]
     lib.icpk_matrix_to_quaternion.restype = None
@@ -220,6 +222,19 @@ def default_params(**kw):
 
 
 # ---- host helpers (no device) ------------------------------------------------
+def backproject_keypoints(depth, kp_xy, fx=468.60, cx=318.27):
+    """pointcloud.cpp:60-98 (host only): (points (3, m) float32, kept (m,) indices into kp_xy)."""
+    depth = np.ascontiguousarray(depth, np.uint16)
+    kp = np.ascontiguousarray(kp_xy, np.float32).reshape(-1, 2)
+    out = np.zeros((max(len(kp), 1), 3), np.float32)
+    kept = np.zeros(max(len(kp), 1), np.int32)
+    m = load().icpk_backproject_keypoints(depth.ctypes.data_as(C.POINTER(C.c_uint16)), depth.shape[0], depth.shape[1], _fp(kp),
+                                          len(kp), fx, cx, _fp(out), kept.ctypes.data_as(C.POINTER(C.c_int32)))
+    if m < 0:
+        raise IcpkError(m, "icpk_backproject_keypoints")
+    return np.ascontiguousarray(out[:m].T), kept[:m].copy()
+
+
 def make_rotation_matrix(x, y, z):
     out = np.zeros(9, np.float32)
     load().icpk_make_rotation_matrix(x, y, z, _fp(out))

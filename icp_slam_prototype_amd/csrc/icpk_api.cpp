@@ -2652,6 +2652,28 @@ float icpk_distance3(const float a[3], const float b[3]) {
 }
 
 void icpk_make_rotation_matrix(float x, float y, float z, float out[9]) { make_rotation_matrix(x, y, z, out); }
+int icpk_backproject_keypoints(const uint16_t* depth, int32_t rows, int32_t cols, const float* kp_xy, int32_t n, float fx,
+                               float cx, float* out_xyz, int32_t* kept) {
+  if (!depth || rows <= 0 || cols <= 0 || n < 0 || (n > 0 && (!kp_xy || !out_xyz))) return ICPK_E_ARG;
+  int m = 0;
+  for (int i = 0; i < n; ++i) {
+    const float fxp = kp_xy[2 * i], fyp = kp_xy[2 * i + 1];
+    if (!(fxp > -1.f && fxp < (float)cols + 1.f && fyp > -1.f && fyp < (float)rows + 1.f)) continue;  // (NaN, far outside)
+    const long x = std::lrint(fxp), y = std::lrint(fyp);  // cvRound: to nearest, ties to even (default rounding mode)
+    if (x < 0 || x >= cols || y < 0 || y >= rows) continue;
+    const uint16_t d = depth[(size_t)y * cols + x];
+    if (d == 0) continue;  // pointcloud.cpp:67-70
+    const float pz = ((float)d) / 5000.0f;            // pointcloud.cpp:86
+    const float px = ((float)x - cx) * pz / fx;       // :87 (an int minus the float constant)
+    const float py = ((float)y - cx) * pz / fx;       // :88 (CX, FX)
+    out_xyz[3 * m] = px;
+    out_xyz[3 * m + 1] = py;
+    out_xyz[3 * m + 2] = pz;
+    if (kept) kept[m] = i;
+    ++m;
+  }
+  return m;
+}
 void icpk_matrix_to_quaternion(const float m[9], float q[4]) { matrix_to_quaternion(m, q); }
 void icpk_quaternion_to_euler(const float q[4], float e[3]) { quaternion_to_euler(q, e); }
 void icpk_solve_reference(const float M[9], float R[9]) { solve_reference(M, R); }

@@ -194,6 +194,13 @@ inline int filterDepthImage(Engine& eng, uint16_t* image, int rows, int cols, in
   return icpk_filter_depth_image(eng.ctx(), image, image, rows, cols, maxDistance, minDistance, 1, -1, -1);
 }
 
+// pointcloud.cpp:60-98: the 3-D points of a frame's key points (cv::KeyPoint::pt as (x, y) pairs), the cloud that
+// findGlobalKeyPointAssociations below takes as dataKeypoints.  Host only.  out_xyz: n x 3 floats, kept: n ints or null.
+inline int backprojectKeyPoints(const uint16_t* depth, int rows, int cols, const float* kp_xy, int n, float* out_xyz,
+                                int32_t* kept = nullptr, float fx = ICPK_FX, float cx = ICPK_CX) {
+  return icpk_backproject_keypoints(depth, rows, cols, kp_xy, n, fx, cx, out_xyz, kept);
+}
+
 // icp.cpp:488-515: data key points vs map key points.  errors / associations are rebuilt (pairs of
 // (query index, nearest index) in query order), nonAssociations is appended to; an empty map
 // returns ICPK_W_EMPTY_MAP and touches nothing (icp.cpp:490-491).

@@ -372,6 +372,14 @@ float icpk_distance3(const float a[3], const float b[3]);                       
 void icpk_make_rotation_matrix(float x_deg, float y_deg, float z_deg, float out[9]); /* icp.cpp:640-653      */
 void icpk_matrix_to_quaternion(const float m[9], float q_wxyz[4]);                 /* quaternion.cpp:23-79 */
 void icpk_quaternion_to_euler(const float q_wxyz[4], float e_deg[3]);              /* SLAM.cpp:613-636     */
+/* pointcloud.cpp:60-98: the 3-D points of a frame's key points (what findGlobalKeyPointAssociations, icp.cpp:488,
+ * is fed).  kp_xy: n pixel positions (x, y) as cv::KeyPoint::pt holds them; each is rounded to a pixel as the
+ * reference's Point2f -> Point2i conversion does (cvRound: to nearest, ties to even), dropped if its depth is 0
+ * (:67-70) -- or if it falls outside the image, where the reference reads out of bounds -- and back-projected with
+ * the formula of :86-88 (CX and FX for y too).  out_xyz: room for n points (x, y, z interleaved); kept (or NULL):
+ * the index into kp_xy of every point written.  Returns the number of points (>= 0) or a negative status.  Host only. */
+int icpk_backproject_keypoints(const uint16_t *depth, int32_t rows, int32_t cols, const float *kp_xy, int32_t n,
+                               float fx, float cx, float *out_xyz, int32_t *kept);
 /* host solve exposed for testing: reference flavour from the float moment,
  * Kabsch flavour from raw sums (n, sum a, sum b, sum a b^T) */
 void icpk_solve_reference(const float M[9], float R[9]);                           /* icp.cpp:215-223      */

@@ -254,6 +254,30 @@ def to_euler(q):
     return e
 
 
+def backproject_keypoints(depth, kp_xy, fx=468.60, cx=318.27):
+    """pointcloud.cpp:60-98: key points (x, y pixel positions as cv::KeyPoint::pt holds them) -> Point2i by cvRound
+    (to nearest, ties to even), depth 0 skipped (:67-70), back-projected by :86-88 in float32, in list order.  Pixels
+    outside the image (undefined in the reference) are skipped.  Returns (points (3, m), kept indices)."""
+    depth = np.ascontiguousarray(depth, np.uint16)
+    rows, cols = depth.shape
+    kp = np.asarray(kp_xy, np.float32).reshape(-1, 2)
+    pts, kept = [], []
+    f32 = np.float32
+    for i, (xf, yf) in enumerate(kp):
+        if not (np.isfinite(xf) and np.isfinite(yf)):
+            continue
+        x, y = int(np.rint(xf)), int(np.rint(yf))
+        if not (0 <= x < cols and 0 <= y < rows) or depth[y, x] == 0:
+            continue
+        pz = f32(depth[y, x]) / f32(5000.0)
+        px = (f32(x) - f32(cx)) * pz / f32(fx)
+        py = (f32(y) - f32(cx)) * pz / f32(fx)
+        pts.append((px, py, pz))
+        kept.append(i)
+    out = np.array(pts, np.float32).reshape(-1, 3).T
+    return np.ascontiguousarray(out), np.array(kept, np.int32)
+
+
 def subsample_keep(rows, cols, factor, seed, stream):
     """The seeded stand-in for pointcloud.cpp:27-30 (`rand() % SUBSAMPLE_FACTOR`) as include/icpk.h defines it for
     icpk_set_subsample: uint8 mask over the rows x cols pixels of image number `stream` (0-based count of the images

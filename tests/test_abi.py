@@ -77,6 +77,33 @@ def test_host_helpers_match_oracle(lib, oracle):
         assert np.linalg.norm(a.astype(np.float64) - b.astype(np.float64)) < 1e-5
 
 
+def test_keypoint_backprojection_matches_oracle(lib, oracle):
+    """pointcloud.cpp:60-98 (host helper, no device): rounding of the key point to a pixel (ties to even), empty pixels
+    and positions outside the image skipped, the full-cloud formula -- equal to the oracle's restatement bit for bit and
+    to the full back-projection at the same pixels."""
+    rng = np.random.default_rng(3)
+    rows, cols = 48, 64
+    depth = rng.integers(500, 30000, (rows, cols)).astype(np.uint16)
+    depth[rng.random(depth.shape) < 0.3] = 0
+    kp = np.stack([rng.uniform(-3, cols + 3, 300), rng.uniform(-3, rows + 3, 300)], 1).astype(np.float32)
+    kp[:8] = [[0.5, 0.5], [1.5, 2.5], [62.5, 46.5], [63.49, 47.49], [63.5, 47.0], [-0.5, 0.0], [np.nan, 3.0], [5.0, np.inf]]
+    got, kept = binding.backproject_keypoints(depth, kp)
+    want, wkept = oracle.backproject_keypoints(depth, kp)
+    assert np.array_equal(kept, wkept) and got.tobytes() == want.tobytes() and 100 < len(kept) < 300
+    # the same numbers as the cloud's own points at those pixels (pointcloud.cpp:37-39 == :86-88)
+    full = oracle.backproject(depth)
+    rank = np.cumsum(depth.reshape(-1) != 0) - 1
+    for k, i in enumerate(kept[:50]):
+        x, y = int(np.rint(kp[i, 0])), int(np.rint(kp[i, 1]))
+        assert np.array_equal(got[:, k], full[:, rank[y * cols + x]])
+    # ties to even: 0.5 -> 0, 1.5 -> 2, 2.5 -> 2
+    d = np.arange(1, 13, dtype=np.uint16).reshape(3, 4) * 1000
+    p, k = binding.backproject_keypoints(d, np.float32([[0.5, 0.5], [1.5, 2.5], [2.5, 1.5]]))
+    assert [float(v) for v in p[2]] == [float(np.float32(d[0, 0]) / np.float32(5000)), float(np.float32(d[2, 2]) / np.float32(5000)),
+                                        float(np.float32(d[2, 2]) / np.float32(5000))]
+    assert binding.backproject_keypoints(d, np.zeros((0, 2), np.float32))[0].shape == (3, 0)
+
+
 def test_host_kabsch_matches_reference_python_golden(lib):
     """PINNED by the outputs of the reference's rigid_transform_3D.py."""
     g = np.load(os.path.join(GOLD, "kabsch_golden.npz"))
