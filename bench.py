@@ -679,7 +679,7 @@ def tracker_path_native(frames, gpu_index, rounds=8, filt=False, resident=True):
             f.write(np.ascontiguousarray(d, np.uint16).tobytes())
         f.flush()
         out = subprocess.run([exe, f.name, str(rows), str(cols), str(len(frames)), str(rounds), str(int(filt)),
-                              str(int(resident)), str(gpu_index)], capture_output=True, text=True, timeout=300)
+                              str(int(resident)), str(gpu_index)], capture_output=True, text=True, timeout=120)
     if out.returncode != 0:
         raise RuntimeError(f"tracker_bench rc {out.returncode}: {out.stderr[-300:]}")
     return json.loads(out.stdout.strip().splitlines()[-1])
