@@ -216,7 +216,10 @@ int icpk_associate_keypoints(icpk_ctx *ctx, int32_t nn_mode, float max_dist, int
 /* Starts from the source as uploaded (icpk_reset_source), leaves the aligned
  * source on the device.  T_out: row-major 4x4, same content as the CV_32FC1
  * matrix icp::getTransformation returns (icp.cpp:29,227-233,266-268) with row
- * 3 = (0,0,0,1) instead of uninitialised memory.  stats may be NULL. */
+ * 3 = (0,0,0,1) instead of uninitialised memory.  stats may be NULL.
+ * Returns as soon as T_out / stats / the trace are final (the device writes them into pinned, mapped host memory);
+ * the last launches of the call -- the caller-order copy of the aligned source among them -- may still be running,
+ * and every later call on this context is ordered behind them (icpk_get_source and icpk_get_associations wait). */
 int icpk_align(icpk_ctx *ctx, const icpk_params *p, float T_out[16], icpk_stats *stats);
 /* Per-iteration record of the last icpk_align: for iteration i < *n_iter,
  * R_out[9*i..] is the rotation found (icp.cpp:218-223, before inversion),
