@@ -607,12 +607,6 @@ __device__ __forceinline__ void nn_grid_body(
   // planes here.  sp_in / sp_out: the seed of every query as a point (x, y, z, target index) in
   // the same order: the match of the previous sweep, written by that sweep.  best_m: the
   // results in scan order (seeds of a following sweep that does not continue the chain).
-  bool apply_rt = false, stop_after = false;
-  if (st) {
-    if (st->done) return;
-    stop_after = st->stop_after_transform != 0;
-    apply_rt = st->iterations > 0 || stop_after;
-  }
   constexpr int NQ = 64 / S;
   const int lane = threadIdx.x & 63;
   // the S lanes of a query are ADJACENT lanes: they read S consecutive targets (one or two
@@ -622,15 +616,35 @@ __device__ __forceinline__ void nn_grid_body(
   const int ip = wave_id * NQ + lane / S;
   GRID_STAMP(0);
   const bool live = ip < nq;
+  // (query and seed are asked for BEFORE the loop state is looked at: the state's scalar loads and these two are cold
+  // round trips that can run side by side; after the loop's end the two loads were for nothing)
   const float4 q4 = live ? qm4[ip] : make_float4(0.f, 0.f, 0.f, 0.f);
   const float4 s4 = live ? sp_in[ip] : make_float4(0.f, 0.f, 0.f, 0.f);
+  // (... as is the grid's geometry, wanted only after the seed distance is known; and the state is read in ONE go --
+  // flags, translation, rotation -- not flag by flag behind branches: three dependent scalar round trips became one)
+  const GridInfo g = *gi;
+  asm volatile("" ::"s"(g.lo[0]), "s"(g.lo[1]), "s"(g.lo[2]), "s"(g.inv_h), "s"(g.h), "s"(g.inv_hx), "s"(g.xdiv), "s"(g.nx), "s"(g.ny),
+               "s"(g.nz));
+  bool apply_rt = false, stop_after = false;
+  double Rd[9] = {1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0};
+  float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+  if (st) {
+    const int done = st->done, stop = st->stop_after_transform, iters = st->iterations;
+    t0 = st->rt.t[0], t1 = st->rt.t[1], t2 = st->rt.t[2];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Rd[k] = st->Rd[k];
+    // (all of them HERE: left alone the compiler sinks each load behind the branch that first needs it)
+    asm volatile("" ::"s"(done), "s"(stop), "s"(iters), "s"(t0), "s"(t1), "s"(t2), "s"(Rd[0]), "s"(Rd[1]), "s"(Rd[2]), "s"(Rd[3]),
+                 "s"(Rd[4]), "s"(Rd[5]), "s"(Rd[6]), "s"(Rd[7]), "s"(Rd[8]));
+    if (done) return;
+    stop_after = stop != 0;
+    apply_rt = iters > 0 || stop_after;
+  }
   const int i = __float_as_int(q4.w);
   float qx = q4.x, qy = q4.y, qz = q4.z;
   if (apply_rt) {  // pointcloud.cpp:321-359: p <- fl32(fl32(R p) + t)
     // (the rotation as the float64 values the step kernel widened once: wave-uniform scalar operands, no per-lane
     // conversions; the same numbers, hence the same bits)
-    const double* __restrict__ Rd = st->Rd;
-    const float t0 = st->rt.t[0], t1 = st->rt.t[1], t2 = st->rt.t[2];
     const double px = qx, py = qy, pz = qz;
     qx = (float)__builtin_fma(Rd[2], pz, __builtin_fma(Rd[1], py, Rd[0] * px)) + t0;
     qy = (float)__builtin_fma(Rd[5], pz, __builtin_fma(Rd[4], py, Rd[3] * px)) + t1;
@@ -661,7 +675,6 @@ __device__ __forceinline__ void nn_grid_body(
   // a NaN best distance can never be replaced (d < NaN and d == NaN are false): no scan
   const bool scan = live && bd == bd;
   bool own = slice == 0;  // this lane's (bx, by, bz) is the point of the group's agreed key (see share)
-  const GridInfo g = *gi;
   // The S lanes of a query share the candidates of a cell box evenly.  Rows are taken S at a
   // time: lane k fetches the range of row k, a prefix sum over the S lanes numbers the
   // candidates of the chunk 0 .. C-1, and lane k evaluates candidates k, k + S, k + 2S, ...,
