@@ -32,6 +32,7 @@ int fail(icpk_ctx* ctx, int code, const char* msg) {
 
 int ensure_cloud(icpk_ctx* ctx, Cloud& c, int n) {
   if (ctx && (&c == &ctx->src0 || &c == &ctx->src)) ctx->src_pristine = false;  // (about to be resized or rewritten)
+  if (ctx && &c == &ctx->src) ctx->rec_pending = false;  // (whatever was to be unpacked into it is superseded)
   if (ctx && (&c == &ctx->src0 || &c == &ctx->tgt)) ctx->have_pix_seed = false;  // (other points than the pixel maps describe)
   const int cap = round_up(n < 1 ? 1 : n, NN_TILE);
   if (cap > c.cap) {
@@ -116,6 +117,7 @@ int copy_src0_to_src(icpk_ctx* ctx) {
   // src_pristine: the working copy is known to hold the committed source already (icpk_backproject_pair writes both
   // at once; nothing has touched either since) -- the frame path's icpk_align starts without this copy
   if (ctx->src_pristine && ctx->pristine_skip && ctx->src.n == ctx->src0.n) return ICPK_OK;
+  ctx->rec_pending = false;  // (the working source is overwritten: nothing of the last loop's is wanted any more)
   int rc = ensure_cloud(ctx, ctx->src, ctx->src0.n);
   if (rc) return rc;
   const Cloud &a = ctx->src0, &b = ctx->src;
@@ -332,6 +334,19 @@ int enqueue_cell_order(icpk_ctx* ctx, bool with_points) {
 }
 
 int ensure_query_points(icpk_ctx* ctx, int nq);
+
+// After a device loop of grid sweeps the caller-order views -- the moved source planes, the association keys -- exist
+// only as records (ctx->rec, kernels_grid.hip); they are unpacked when something asks for them (icpk_get_source,
+// icpk_get_associations, icpk_commit_source, icpk_transform_source, icpk_nn, icpk_reduce ...) and dropped when the
+// working source is overwritten first (the next alignment, a new source): a tracker that only wants the pose never
+// pays the launch.  ICPK_LAZY_UNPACK=0: unpack at the end of every loop.
+int ensure_unpacked(icpk_ctx* ctx) {
+  if (!ctx->rec_pending) return ICPK_OK;
+  ctx->rec_pending = false;
+  launch_grid_unpack(ctx->qm4, ctx->rec, ctx->src.n, ctx->src.x(), ctx->src.y(), ctx->src.z(), ctx->best, ctx->stream);
+  ICPK_HIP(ctx, hipGetLastError());
+  return ICPK_OK;
+}
 
 // the deferred initial LoopState of a device loop (device_loop_begin), if no set-up launch has carried it
 int flush_loop_init(icpk_ctx* ctx) {
@@ -927,6 +942,7 @@ int icpk_create(icpk_ctx** out, int device_id) {
   if (const char* e = std::getenv("ICPK_BATCH_SETUP")) ctx->batch_setup = std::atoi(e);  // 0: per-pair launches; 2: batched launches for single-group host-pointer batches too; 3: as 2, replayed pair by pair
   if (const char* e = std::getenv("ICPK_PRISTINE_SKIP")) ctx->pristine_skip = std::atoi(e) != 0;
   if (const char* e = std::getenv("ICPK_PIXEL_SEEDS")) ctx->pixel_seeds = std::atoi(e) != 0;
+  if (const char* e = std::getenv("ICPK_LAZY_UNPACK")) ctx->lazy_unpack = std::atoi(e) != 0;
   if (const char* e = std::getenv("ICPK_IMAGE_ORDER")) ctx->image_order = std::atoi(e) != 0;
   if (const char* e = std::getenv("ICPK_ZERO_COPY_UPLOAD")) ctx->zero_copy_upload = std::atoi(e) != 0;
   if (const char* e = std::getenv("ICPK_RESULT_MIRROR")) ctx->result_mirror = std::atoi(e) != 0;
@@ -1045,6 +1061,7 @@ int icpk_commit_source(icpk_ctx* ctx) {
   if (!ctx) return ICPK_E_ARG;
   if (!ctx->have_src) return fail(ctx, ICPK_E_NOT_SET, "source cloud not set");
   ICPK_HIP(ctx, hipSetDevice(ctx->device));
+  if (int ru = ensure_unpacked(ctx)) return ru;
   const Cloud &a = ctx->src, &b = ctx->src0;  // src0.cap >= src.cap by construction
   const int m = round_up(a.n < 1 ? 1 : a.n, NN_TILE);
   ICPK_HIP(ctx, hipMemcpyAsync(b.x(), a.x(), (size_t)m * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
@@ -1058,6 +1075,7 @@ int icpk_get_source(icpk_ctx* ctx, float* x, float* y, float* z) {
   if (!ctx || !x || !y || !z) return ICPK_E_ARG;
   if (!ctx->have_src) return fail(ctx, ICPK_E_NOT_SET, "source cloud not set");
   ICPK_HIP(ctx, hipSetDevice(ctx->device));
+  if (int ru = ensure_unpacked(ctx)) return ru;
   const size_t b = (size_t)ctx->src.n * sizeof(float);
   if (b) {
     ICPK_HIP(ctx, hipMemcpyAsync(x, ctx->src.x(), b, hipMemcpyDeviceToHost, ctx->stream));
@@ -1090,10 +1108,9 @@ int icpk_get_associations(icpk_ctx* ctx, int32_t* idx_out, float* dist_out) {
   if (!ctx->have_assoc) return fail(ctx, ICPK_E_NOT_SET, "no nearest-neighbour sweep has run");
   ICPK_HIP(ctx, hipSetDevice(ctx->device));
   const int nq = ctx->src.n;
-  if (ctx->rec_pending) {  // a frame-batch slot after its lock-step loop
-    launch_grid_unpack(ctx->qm4, ctx->rec, nq, ctx->src.x(), ctx->src.y(), ctx->src.z(), ctx->best, ctx->stream);
-    ICPK_HIP(ctx, hipGetLastError());
-    ctx->rec_pending = false;
+  {
+    const int ru = ensure_unpacked(ctx);  // (after a device loop of grid sweeps; a frame-batch slot after its lock-step loop)
+    if (ru) return ru;
   }
   if (nq > 0) {
     // K2 unpacks (distance, index) keys into the idx/dist planes
@@ -1112,6 +1129,7 @@ int icpk_nn(icpk_ctx* ctx, int32_t nn_mode, int32_t* idx_out, float* dist_out) {
   int rc = check_ready(ctx);
   if (rc) return rc;
   ICPK_HIP(ctx, hipSetDevice(ctx->device));
+  if (int ru = ensure_unpacked(ctx)) return ru;
   rc = enqueue_nn(ctx, nn_mode);
   if (rc) return rc;
   if (idx_out || dist_out) return icpk_get_associations(ctx, idx_out, dist_out);
@@ -1123,6 +1141,7 @@ int icpk_reduce(icpk_ctx* ctx, float max_dist, double* sums, int64_t* count) {
   if (!ctx || !sums) return ICPK_E_ARG;
   if (!ctx->have_assoc) return fail(ctx, ICPK_E_NOT_SET, "no nearest-neighbour sweep has run");
   ICPK_HIP(ctx, hipSetDevice(ctx->device));
+  if (int ru = ensure_unpacked(ctx)) return ru;
   if (ctx->src.n == 0) {
     std::memset(sums, 0, NSUM * sizeof(double));
     if (count) *count = 0;
@@ -1140,6 +1159,7 @@ int icpk_transform_source(icpk_ctx* ctx, const float R[9], const float t[3]) {
   if (!ctx || !R || !t) return ICPK_E_ARG;
   if (!ctx->have_src) return fail(ctx, ICPK_E_NOT_SET, "source cloud not set");
   ICPK_HIP(ctx, hipSetDevice(ctx->device));
+  if (int ru = ensure_unpacked(ctx)) return ru;
   Rt rt;
   std::memcpy(rt.R, R, sizeof(rt.R));
   std::memcpy(rt.t, t, sizeof(rt.t));
@@ -1379,8 +1399,10 @@ static int align_device_loop(icpk_ctx* ctx, const icpk_params* p, float T_out[16
     done_seen = (w1 >> 2) == ctx->loop_epoch && (w1 & 2);
   }
   if (!done_seen) launch_loop_step(ctx->partial, ctx->pcount, B, nsum, ctx->st_dev, 1, ctx->stream);
-  if (loop_rec(ctx))  // the caller-order planes and keys the grid sweeps did not keep current, once
-    launch_grid_unpack(ctx->qm4, ctx->rec, ctx->src.n, ctx->src.x(), ctx->src.y(), ctx->src.z(), ctx->best, ctx->stream);
+  if (loop_rec(ctx)) {  // the caller-order planes and keys the grid sweeps did not keep current: once, and only if asked for
+    ctx->rec_pending = true;
+    if (!ctx->lazy_unpack && (rc = ensure_unpacked(ctx))) return rc;
+  }
   ICPK_HIP(ctx, hipGetLastError());
   const LoopState* result = nullptr;
   if (mirror) {
@@ -2519,6 +2541,7 @@ int icpk_associate_keypoints(icpk_ctx* ctx, int32_t nn_mode, float max_dist, int
   // icp.cpp:490-491: an empty map returns BEFORE errors / associations are cleared: nothing is touched
   if (ctx->tgt.n <= 0) return ICPK_W_EMPTY_MAP;
   ICPK_HIP(ctx, hipSetDevice(ctx->device));
+  if (int ru = ensure_unpacked(ctx)) return ru;
   const int nq = ctx->src.n;
   if (nq == 0) {  // icp.cpp:497-498: the lists are cleared, nothing is appended
     *n_assoc = 0;
@@ -2604,6 +2627,7 @@ int icpk_reduce_p2l(icpk_ctx* ctx, float max_dist, double* sums, int64_t* count)
   if (!ctx->have_assoc) return fail(ctx, ICPK_E_NOT_SET, "no nearest-neighbour sweep has run");
   if (!ctx->have_normals) return fail(ctx, ICPK_E_NOT_SET, "no target normals");
   ICPK_HIP(ctx, hipSetDevice(ctx->device));
+  if (int ru = ensure_unpacked(ctx)) return ru;
   if (ctx->src.n == 0) {
     std::memset(sums, 0, NP2L * sizeof(double));
     if (count) *count = 0;

@@ -90,6 +90,7 @@ struct icpk_ctx {
   int pix_cap = 0;
   bool have_pix_seed = false;          // they describe the clouds the context holds now
   bool image_order = true;             // ICPK_IMAGE_ORDER=0: sort the queries of an image-ordered source by cell like any other (diagnostic)
+  bool lazy_unpack = true;             // ICPK_LAZY_UNPACK=0: unpack the records at the end of every device loop (diagnostic)
   bool pixel_seeds = true;             // ICPK_PIXEL_SEEDS=0: the reference's literal seed (diagnostic)
   int pix_rows = 0, pix_cols = 0;
   bool src_pristine = false;     // the working source equals the committed one (see copy_src0_to_src)
@@ -130,7 +131,7 @@ struct icpk_ctx {
   float4* sp_in = nullptr;   // seeds as points, scan order: read by the next grid sweep
   float4* sp_out = nullptr;  // ... written by it
   float4* rec = nullptr;     // device loop behind grid sweeps: caller-order records {(query, distance), (match, index)}, 2 float4 per query -- what K2 reads
-  bool rec_pending = false;  // frame-batch slot: the loop left planes / keys to be unpacked from qm4 / rec on demand (icpk_get_associations)
+  bool rec_pending = false;  // the last device loop left planes / keys to be unpacked from qm4 / rec on demand (ensure_unpacked)
   int qm4_cap = 0;
   // frame-batch mode: child contexts (one per pair in flight; own stream for set-up work) --
   // owned by the parent, never handed out

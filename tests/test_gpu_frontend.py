@@ -297,9 +297,11 @@ def test_align_after_backproject_pair_skips_the_source_copy_only_when_it_may(mon
               ]
     script2 = [["nn", "align"], ["set", "align", "transform", "commit", "align"], ["reset", "transform", "align"]]
     monkeypatch.setenv("ICPK_PRISTINE_SKIP", "0")
+    monkeypatch.setenv("ICPK_LAZY_UNPACK", "0")  # (the aligned source unpacked at the end of every loop, not when asked for)
     with binding.Context(0) as c:
         want = run(c, script) + run(c, script2)
     monkeypatch.setenv("ICPK_PRISTINE_SKIP", "1")
+    monkeypatch.setenv("ICPK_LAZY_UNPACK", "1")
     with binding.Context(0) as c:
         got = run(c, script) + run(c, script2)
     assert len(got) == len(want) == 10
@@ -308,8 +310,9 @@ def test_align_after_backproject_pair_skips_the_source_copy_only_when_it_may(mon
 
 
 @pytest.mark.parametrize("env", [{"ICPK_PIXEL_SEEDS": "0"}, {"ICPK_ZERO_COPY_UPLOAD": "0"}, {"ICPK_RESULT_MIRROR": "0"}, {"ICPK_IMAGE_ORDER": "0"},
+                                 {"ICPK_LAZY_UNPACK": "0"},
                                  {"ICPK_PIXEL_SEEDS": "0", "ICPK_ZERO_COPY_UPLOAD": "0", "ICPK_RESULT_MIRROR": "0", "ICPK_PRISTINE_SKIP": "0",
-                                  "ICPK_IMAGE_ORDER": "0"}])
+                                  "ICPK_IMAGE_ORDER": "0", "ICPK_LAZY_UNPACK": "0"}])
 @pytest.mark.parametrize("filt", [False, True])
 def test_frame_path_shortcuts_do_not_change_results(env, filt, monkeypatch):
     """Image-space seeds for the first sweep, the zero-copy upload, the outputs through mapped host memory and the
