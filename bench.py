@@ -661,11 +661,12 @@ def tracker_path(gpu_index):
                        "threshold exit; host depth images in, 4x4 + trace out; plain / with_filterDepthImage: the previous frame "
                        "stays on the device (one upload per call); both_frames_uploaded: as round 2 measured it; these three "
                        "through Python / ctypes (host_ms_per_call includes ~15 us of interpreter per call), native_cpp: the "
-                       "same C-ABI calls from tests/cpp/tracker_bench.cpp")
+                       "same C-ABI calls from tests/cpp/tracker_bench.cpp (native_cpp.registered_frame_buffers: the frames in memory the caller "
+                       "pinned once with icpk_register_host_buffer)")
     return res
 
 
-def tracker_path_native(frames, gpu_index, rounds=8, filt=False, resident=True):
+def tracker_path_native(frames, gpu_index, rounds=8, filt=False, resident=True, registered=False):
     """tests/cpp/tracker_bench.cpp (prebuilt by __graft_entry__.build(); rebuilt here with g++ if missing) on `frames`."""
     import subprocess
     import tempfile
@@ -679,7 +680,7 @@ def tracker_path_native(frames, gpu_index, rounds=8, filt=False, resident=True):
             f.write(np.ascontiguousarray(d, np.uint16).tobytes())
         f.flush()
         out = subprocess.run([exe, f.name, str(rows), str(cols), str(len(frames)), str(rounds), str(int(filt)),
-                              str(int(resident)), str(gpu_index)], capture_output=True, text=True, timeout=120)
+                              str(int(resident)), str(gpu_index), str(int(registered))], capture_output=True, text=True, timeout=120)
     if out.returncode != 0:
         raise RuntimeError(f"tracker_bench rc {out.returncode}: {out.stderr[-300:]}")
     return json.loads(out.stdout.strip().splitlines()[-1])
@@ -948,7 +949,10 @@ def main():
         # the frame path from a C++ caller, measured while nothing else holds the GPU (see tracker_path)
         global _NATIVE_TRACKER
         try:
-            _NATIVE_TRACKER = dict(tracker_path_native(tracker_frames(), local_rank, rounds=8), beside_the_bench_process=False)
+            fr = tracker_frames()
+            _NATIVE_TRACKER = dict(tracker_path_native(fr, local_rank, rounds=8), beside_the_bench_process=False)
+            # ... and for a caller whose frame buffers are long-lived and pinned once (icpk_register_host_buffer): no staging copy
+            _NATIVE_TRACKER["registered_frame_buffers"] = tracker_path_native(fr, local_rank, rounds=8, registered=True)
         except Exception as e:
             _NATIVE_TRACKER = {"error": repr(e)[:300]}
 

@@ -36,7 +36,7 @@ SYMBOLS = [
     "icpk_align_batch", "icpk_align_batch_device", "icpk_backproject", "icpk_backproject_with_normals", "icpk_set_target_normals",
     "icpk_get_target_normals", "icpk_reduce_p2l", "icpk_solve_point_to_plane", "icpk_pair_distance", "icpk_pair_distance3", "icpk_distance3", "icpk_make_rotation_matrix",
     "icpk_matrix_to_quaternion", "icpk_quaternion_to_euler", "icpk_solve_reference", "icpk_solve_kabsch",
-    "icpk_associate_keypoints", "icpk_filter_depth_image", "icpk_backproject_filtered", "icpk_backproject_pair", "icpk_set_subsample", "icpk_backproject_keypoints",
+    "icpk_associate_keypoints", "icpk_filter_depth_image", "icpk_backproject_filtered", "icpk_backproject_pair", "icpk_set_subsample", "icpk_backproject_keypoints", "icpk_register_host_buffer", "icpk_unregister_host_buffer",
     "icpk_comm_unique_id", "icpk_comm_init_rccl", "icpk_comm_destroy", "icpk_comm_rank", "icpk_comm_world",
     "icpk_comm_partition", "icpk_comm_broadcast_target", "icpk_comm_gather_results", "icpk_comm_allreduce_sums",
     "icpk_comm_barrier", "icpk_align_query_sharded",
@@ -134,6 +134,8 @@ def load():
     lib.icpk_align_batch.argtypes = [C.c_void_p, C.c_int32, C.POINTER(Pair), C.POINTER(Params), fp, C.POINTER(Stats)]
     lib.icpk_align_batch_device.argtypes = lib.icpk_align_batch.argtypes
     lib.icpk_set_subsample.argtypes = [C.c_void_p, C.c_int32, C.c_uint64]
+    lib.icpk_register_host_buffer.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    lib.icpk_unregister_host_buffer.argtypes = [C.c_void_p, C.c_void_p]
     lib.icpk_backproject.argtypes = [C.c_void_p, C.POINTER(C.c_uint16), C.c_int32, C.c_int32, C.c_float, C.c_float,
                                      fp, C.c_int32]
     lib.icpk_pair_distance.argtypes = [C.c_void_p, fp, fp, fp, C.c_int32]
@@ -424,6 +426,16 @@ class Context:
         fn = self._lib.icpk_pair_distance3 if point3 else self._lib.icpk_pair_distance
         self._chk(fn(self._h, _fp(a), _fp(b), _fp(out), n))
         return out
+
+    def register_host_buffer(self, arr):
+        """Pins a C-contiguous numpy array for the device (icpk_register_host_buffer): depth images that lie inside it
+        are read by icpk_backproject_pair where they are.  Keep the array alive until unregister_host_buffer / close."""
+        if not arr.flags["C_CONTIGUOUS"]:
+            raise ValueError("a C-contiguous array expected")
+        self._chk(self._lib.icpk_register_host_buffer(self._h, arr.ctypes.data, arr.nbytes))
+
+    def unregister_host_buffer(self, arr):
+        self._chk(self._lib.icpk_unregister_host_buffer(self._h, arr.ctypes.data))
 
     def set_subsample(self, factor=40, seed=0):
         """pointcloud.cpp:27-30 with a reproducible choice: every back-projection keeps one valid pixel in `factor`

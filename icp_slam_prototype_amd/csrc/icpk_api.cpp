@@ -983,6 +983,8 @@ void icpk_destroy(icpk_ctx* ctx) {
   if (ctx->st_mirror) (void)hipHostFree(ctx->st_mirror);
   if (ctx->grid_ticket) (void)hipFree(ctx->grid_ticket);
   if (ctx->stage_depth) (void)hipHostFree(ctx->stage_depth);
+  for (const icpk_ctx::HostRange& r : ctx->registered) (void)hipHostUnregister(const_cast<char*>(r.host));
+  ctx->registered.clear();
   if (ctx->pix_tidx) (void)hipFree(ctx->pix_tidx);
   if (ctx->pix_src) (void)hipFree(ctx->pix_src);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -2257,6 +2259,42 @@ static unsigned long long next_subsample_key(icpk_ctx* ctx) {
   return ctx->sub_seed + (k + 1ull) * 0x9E3779B97F4A7C15ull;
 }
 
+// caller memory that icpk_register_host_buffer pinned: the device address of [p, p + bytes) or nullptr
+static const void* registered_device_pointer(const icpk_ctx* ctx, const void* p, size_t bytes) {
+  const char* c = static_cast<const char*>(p);
+  for (const icpk_ctx::HostRange& r : ctx->registered)
+    if (c >= r.host && c + bytes <= r.host + r.bytes) return r.dev + (c - r.host);
+  return nullptr;
+}
+
+int icpk_register_host_buffer(icpk_ctx* ctx, const void* ptr, size_t bytes) {
+  if (!ctx || !ptr || bytes == 0) return ICPK_E_ARG;
+  ICPK_HIP(ctx, hipSetDevice(ctx->device));
+  if (registered_device_pointer(ctx, ptr, bytes)) return ICPK_OK;
+  ICPK_HIP(ctx, hipHostRegister(const_cast<void*>(ptr), bytes, hipHostRegisterMapped));
+  void* dev = nullptr;
+  const hipError_t e = hipHostGetDevicePointer(&dev, const_cast<void*>(ptr), 0);
+  if (e != hipSuccess) {
+    (void)hipHostUnregister(const_cast<void*>(ptr));
+    return fail(ctx, ICPK_E_HIP, hipGetErrorString(e));
+  }
+  ctx->registered.push_back({static_cast<const char*>(ptr), bytes, static_cast<const char*>(dev)});
+  return ICPK_OK;
+}
+
+int icpk_unregister_host_buffer(icpk_ctx* ctx, const void* ptr) {
+  if (!ctx || !ptr) return ICPK_E_ARG;
+  for (size_t k = 0; k < ctx->registered.size(); ++k)
+    if (ctx->registered[k].host == static_cast<const char*>(ptr)) {
+      ICPK_HIP(ctx, hipSetDevice(ctx->device));
+      ICPK_HIP(ctx, hipStreamSynchronize(ctx->stream));  // (nothing in flight may still read it)
+      ICPK_HIP(ctx, hipHostUnregister(const_cast<void*>(ptr)));
+      ctx->registered.erase(ctx->registered.begin() + k);
+      return ICPK_OK;
+    }
+  return fail(ctx, ICPK_E_ARG, "not a registered buffer");
+}
+
 int icpk_set_subsample(icpk_ctx* ctx, int32_t factor, uint64_t seed) {
   if (!ctx || factor < 0) return ICPK_E_ARG;
   ctx->sub_factor = factor;
@@ -2399,9 +2437,13 @@ int icpk_backproject_pair(icpk_ctx* ctx, const uint16_t* depth_source, const uin
   }
   // without the filter the images are not copied at all: the counting pass reads them from the staging buffer
   const bool zero_copy = !filter && ctx->zero_copy_upload;
+  // (an image inside memory the caller has registered -- icpk_register_host_buffer -- is read where it lies: no copy at all)
+  const uint16_t* reg_s = zero_copy ? static_cast<const uint16_t*>(registered_device_pointer(ctx, depth_source, bytes)) : nullptr;
+  const uint16_t* reg_t =
+      zero_copy && !resident ? static_cast<const uint16_t*>(registered_device_pointer(ctx, depth_target, bytes)) : nullptr;
   auto upload = [&](uint16_t* dev, const uint16_t* host, uint16_t* stage) -> int {
     if (zero_copy) {
-      std::memcpy(stage, host, bytes);
+      if (!(host == depth_source ? reg_s : reg_t)) std::memcpy(stage, host, bytes);
       return ICPK_OK;
     }
     const int parts = npix >= 65536 ? 2 : 1;  // (more parts cost more in copy commands than they hide)
@@ -2436,10 +2478,10 @@ int icpk_backproject_pair(icpk_ctx* ctx, const uint16_t* depth_source, const uin
   const uint16_t* stage_dev = nullptr;
   if (zero_copy) ICPK_HIP(ctx, hipHostGetDevicePointer((void**)&stage_dev, ctx->stage_depth, 0));
   b.im[0] = BpImage{img_s, ctx->src0.x(), ctx->src0.y(), ctx->src0.z(), ctx->src.x(), ctx->src.y(), ctx->src.z(),
-                    ctx->bp_counts, 0.f, ctx->pix_src, nullptr, zero_copy ? stage_dev : nullptr, raw_s, 0, 0, 0};
+                    ctx->bp_counts, 0.f, ctx->pix_src, nullptr, zero_copy ? (reg_s ? reg_s : stage_dev) : nullptr, raw_s, 0, 0, 0};
   b.im[1] = BpImage{img_t, ctx->tgt.x(), ctx->tgt.y(), ctx->tgt.z(), nullptr, nullptr, nullptr,
                     ctx->bp_counts + per_image, __builtin_inff(), nullptr, ctx->pix_tidx,
-                    zero_copy && !resident ? stage_dev + npix : nullptr, raw_t, 0, 0, 0};
+                    zero_copy && !resident ? (reg_t ? reg_t : stage_dev + npix) : nullptr, raw_t, 0, 0, 0};
   // (icp.cpp:38-39 builds the cloud of `data` first, then that of `previous`: the source draws its pattern first)
   b.im[0].sub_key = next_subsample_key(ctx);
   b.im[1].sub_key = next_subsample_key(ctx);

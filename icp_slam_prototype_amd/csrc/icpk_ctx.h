@@ -82,6 +82,12 @@ struct icpk_ctx {
   int sub_factor = 0;                  // icpk_set_subsample: keep one valid pixel in sub_factor (<= 1: all), chosen by ...
   unsigned long long sub_seed = 0;     // ... a hash of this seed, the image's stream number and the pixel
   unsigned long long sub_stream = 0;   // images back-projected since icpk_set_subsample (every image draws a fresh pattern, as rand() would)
+  struct HostRange {                   // icpk_register_host_buffer: caller memory pinned and mapped for the device
+    const char* host;
+    size_t bytes;
+    const char* dev;
+  };
+  std::vector<HostRange> registered;
   bool zero_copy_upload = true;        // ICPK_ZERO_COPY_UPLOAD=0: copy-engine transfer from the staging buffer instead (diagnostic)
   uint16_t* stage_depth = nullptr;     // pinned: icpk_backproject_pair's images on their way to the device
   int stage_depth_cap = 0;

@@ -22,6 +22,7 @@
 #ifndef ICPK_H
 #define ICPK_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -297,6 +298,14 @@ int icpk_align_query_sharded(icpk_ctx *ctx, const icpk_params *p, float T_out[16
  *   (uint32)(z >> 32) % factor == 0
  * -- reproducible, unlike rand(); the stream of the reference's C library is not pinned by anything it ships.
  * factor 0 or 1 (the default): every valid pixel.  Resets k to 0. */
+/* Optional, for callers whose frames live in long-lived buffers (a camera driver's ring, a reused cv::Mat): pins
+ * [ptr, ptr + bytes) and maps it for the device (hipHostRegister).  icpk_backproject_pair then reads a depth image that
+ * lies inside a registered range where it is -- no staging copy, no transfer command; the image has been consumed
+ * when the call returns, as always.  The memory must stay allocated until icpk_unregister_host_buffer (or
+ * icpk_destroy).  Not needed for correctness; results are the same. */
+int icpk_register_host_buffer(icpk_ctx *ctx, const void *ptr, size_t bytes);
+int icpk_unregister_host_buffer(icpk_ctx *ctx, const void *ptr);
+
 #define ICPK_SUBSAMPLE_FACTOR 40 /* pointcloud.hpp:11 */
 int icpk_set_subsample(icpk_ctx *ctx, int32_t factor, uint64_t seed);
 

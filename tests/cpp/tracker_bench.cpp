@@ -5,7 +5,8 @@
 // Host-only C++ over the C ABI; bench.py runs it as a child process, tests/test_gpu_cpp_mirror.py checks that its
 // transforms are the Python path's bit for bit.
 //
-//   tracker_bench <frames.u16> <rows> <cols> <n_frames> <rounds> <filter 0|1> <resident 0|1> [device]
+//   tracker_bench <frames.u16> <rows> <cols> <n_frames> <rounds> <filter 0|1> <resident 0|1> [device [registered 0|1]]
+// registered = 1: the frame buffer is pinned with icpk_register_host_buffer first (a caller with long-lived frame buffers)
 // frames.u16: n_frames images of rows x cols uint16, back to back.  Prints one JSON line.
 #include <chrono>
 #include <cstdint>
@@ -38,6 +39,7 @@ int main(int argc, char** argv) {
   const int rows = std::atoi(argv[2]), cols = std::atoi(argv[3]), nf = std::atoi(argv[4]), rounds = std::atoi(argv[5]);
   const int filter = std::atoi(argv[6]), resident = std::atoi(argv[7]);
   const int device = argc > 8 ? std::atoi(argv[8]) : 0;
+  const int registered = argc > 9 ? std::atoi(argv[9]) : 0;
   if (rows <= 0 || cols <= 0 || nf < 2 || rounds < 1) return 2;
   const size_t px = (size_t)rows * cols;
   std::vector<uint16_t> frames(px * nf);
@@ -52,6 +54,11 @@ int main(int argc, char** argv) {
   int rc = icpk_create(&ctx, device);
   if (rc != ICPK_OK) {
     std::fprintf(stderr, "icpk_create: %d\n", rc);
+    return 1;
+  }
+  if (registered && (rc = icpk_register_host_buffer(ctx, frames.data(), frames.size() * sizeof(uint16_t))) != ICPK_OK) {
+    std::fprintf(stderr, "icpk_register_host_buffer: %d (%s)\n", rc, icpk_last_error(ctx));
+    icpk_destroy(ctx);
     return 1;
   }
   const float camR[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, camP[3] = {5, 5, 5};  // icp.cpp:49, 53

@@ -418,6 +418,44 @@ def test_seeded_subsample_matches_the_oracle(oracle):
             assert c.get_target().tobytes() == oracle.backproject(frames[0], fx=fx, cx=cx).tobytes()
 
 
+def test_registered_host_buffers_give_the_same_clouds():
+    """icpk_register_host_buffer: depth images inside a registered range are read by the device where they lie (no
+    staging copy); frames outside it go through the staging buffer as before -- same clouds, same alignment; a
+    sub-range of a registered buffer counts, an unknown pointer cannot be unregistered."""
+    rows, cols = 120, 160
+    fx, cx = float(synth.FX) * cols / 640, float(synth.CX) * cols / 640
+    rng = np.random.default_rng(41)
+    ring = np.zeros((4, rows, cols), np.uint16)  # (a caller's long-lived frame ring)
+    for k in range(4):
+        d = synth.render_room_depth(rows, cols, synth.rot_xyz_deg(0, 0.5 * k, 0), np.array([0.01 * k, 0, 0]), fx, cx,
+                                    noise_sigma=0.002, rng=rng)
+        d[rng.random(d.shape) > 0.7] = 0
+        ring[k] = d
+    loose = [ring[k].copy() for k in range(4)]
+    R = binding.make_rotation_matrix(1.0, 2.0, -1.0)
+    t = np.array([5.0, 5.0, 5.0], np.float32)
+    with binding.Context(0) as a, binding.Context(0) as b:
+        b.register_host_buffer(ring)
+        b.register_host_buffer(ring)  # (twice is fine)
+        with pytest.raises(binding.IcpkError):
+            b.unregister_host_buffer(loose[0])
+        for k in range(1, 4):
+            for filt in (False, True):
+                want = a.backproject_pair(loose[k], loose[k - 1], R=R, t=t, fx=fx, cx=cx, filter=filt)
+                got = b.backproject_pair(ring[k], ring[k - 1] if k % 2 else loose[k - 1], R=R, t=t, fx=fx, cx=cx, filter=filt)
+                assert got == want
+                assert a.get_source().tobytes() == b.get_source().tobytes() and a.get_target().tobytes() == b.get_target().tobytes()
+                Ta, sa, ra = a.align(max_iterations=10, threshold=1e-5)
+                Tb, sb, rb = b.align(max_iterations=10, threshold=1e-5)
+                assert np.array_equal(Ta, Tb) and (sa.iterations, sa.final_pairs, ra) == (sb.iterations, sb.final_pairs, rb)
+        ring[2] += 7  # (the registered memory is the caller's to change between calls)
+        assert b.backproject_pair(ring[2], ring[1], R=R, t=t, fx=fx, cx=cx) == a.backproject_pair(ring[2].copy(), ring[1].copy(), R=R, t=t, fx=fx, cx=cx)
+        assert a.get_source().tobytes() == b.get_source().tobytes()
+        b.unregister_host_buffer(ring)
+        assert b.backproject_pair(ring[3], ring[2], R=R, t=t, fx=fx, cx=cx) == a.backproject_pair(ring[3], ring[2], R=R, t=t, fx=fx, cx=cx)
+        assert a.get_source().tobytes() == b.get_source().tobytes()
+
+
 def test_backproject_pair_empty_frames_and_bad_arguments():
     z = np.zeros((24, 40), np.uint16)
     d = z.copy()
