@@ -950,9 +950,14 @@ def main():
         global _NATIVE_TRACKER
         try:
             fr = tracker_frames()
-            _NATIVE_TRACKER = dict(tracker_path_native(fr, local_rank, rounds=8), beside_the_bench_process=False)
+
+            def median_run(**kw):  # (a process now and then runs 30-40 % slow from start to end on these boxes: three processes, the median one)
+                runs = sorted((tracker_path_native(fr, local_rank, rounds=8, **kw) for _ in range(3)), key=lambda r: r["frame_pairs_per_s"])
+                return dict(runs[1], runs_frame_pairs_per_s=[round(r["frame_pairs_per_s"], 1) for r in runs])
+
+            _NATIVE_TRACKER = dict(median_run(), beside_the_bench_process=False)
             # ... and for a caller whose frame buffers are long-lived and pinned once (icpk_register_host_buffer): no staging copy
-            _NATIVE_TRACKER["registered_frame_buffers"] = tracker_path_native(fr, local_rank, rounds=8, registered=True)
+            _NATIVE_TRACKER["registered_frame_buffers"] = median_run(registered=True)
         except Exception as e:
             _NATIVE_TRACKER = {"error": repr(e)[:300]}
 
