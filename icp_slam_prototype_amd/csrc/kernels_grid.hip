@@ -681,7 +681,7 @@ __device__ __forceinline__ void nn_grid_body(
   // GB of them per round trip, whatever row they are in.  So a chunk costs one trip for its
   // ranges and ceil(C / (S GB)) trips for its candidates, however unevenly the rows are filled.
 #ifndef ICPK_GRID_GB
-#define ICPK_GRID_GB 5  // (with cells 4x finer along x a query has ~32 candidates: 5 per lane and trip, 70 VGPRs -> 7 waves/SIMD)
+#define ICPK_GRID_GB 5  // (with cells 4x finer along x a query has ~32 candidates: 5 per lane and trip; 64 VGPRs -> 8 waves/SIMD in the steady kernels)
 #endif
   constexpr int GB = ICPK_GRID_GB;
   __shared__ int2 rowtab[64 + 8];  // (+ padding, see the byte count below) per query and row of the chunk: (inclusive prefix, start - exclusive prefix)
