@@ -79,10 +79,13 @@ __device__ __forceinline__ void assoc_reduce_body(
       ++cnt;
   };
   if (rec) {  // (uniform) behind a grid sweep of the device loop: one coalesced 32-byte record per query, no gather
-    if (i_first < nq && f0.w < max_dist) add_pair(f0.x, f0.y, f0.z, f1.x, f1.y, f1.z, f0.w);  // icp.cpp:553 (false for NaN)
-    for (int i = i_first + P; i < nq; i += P) {
-      const float4 r0 = rec[2 * (size_t)i], r1 = rec[2 * (size_t)i + 1];
-      if (r0.w < max_dist) add_pair(r0.x, r0.y, r0.z, r1.x, r1.y, r1.z, r0.w);
+    for (int i = i_first; i < nq; i += P) {  // (the next record is on its way while this one is added)
+      const float4 r0 = f0, r1 = f1;
+      if (i + P < nq) {
+        f0 = rec[2 * (size_t)(i + P)];
+        f1 = rec[2 * (size_t)(i + P) + 1];
+      }
+      if (r0.w < max_dist) add_pair(r0.x, r0.y, r0.z, r1.x, r1.y, r1.z, r0.w);  // icp.cpp:553 (false for NaN)
     }
   } else {
     for (int i = block * RED_THREADS + tid; i < nq; i += P) {
@@ -159,21 +162,34 @@ __global__ __launch_bounds__(RED_THREADS) void p2l_reduce_kernel(
     const float* __restrict__ tz, const float* __restrict__ nxp, const float* __restrict__ nyp,
     const float* __restrict__ nzp, const float4* __restrict__ rec, float max_dist, int32_t* __restrict__ idx_out,
     float* __restrict__ dist_out, double* __restrict__ partial, int* __restrict__ pcount, LoopState* __restrict__ st) {
+  const int tid = threadIdx.x;
+  const int P = gridDim.x * RED_THREADS;
+  // (records path: a lane's first record is asked for before the loop state is looked at, and inside the loop the NEXT
+  // record while the normals of the current one are gathered -- a lane has 3-4 of them at Kinect-v2 size, each a chain of
+  // record -> normal -> arithmetic otherwise)
+  const int i_first = blockIdx.x * RED_THREADS + tid;
+  float4 nx0 = make_float4(0.f, 0.f, 0.f, 0.f), nx1 = nx0;
+  if (rec && i_first < nq) {
+    nx0 = rec[2 * (size_t)i_first];
+    nx1 = rec[2 * (size_t)i_first + 1];
+  }
   if (st) {
     if (st->done | st->stop_after_transform) return;
     if (blockIdx.x == 0 && threadIdx.x == 0) st->sweeps += 1;
   }
-  const int tid = threadIdx.x;
-  const int P = gridDim.x * RED_THREADS;
   double v[NP2L];
 #pragma unroll
   for (int s = 0; s < NP2L; ++s) v[s] = 0.0;
   int cnt = 0;
-  for (int i = blockIdx.x * RED_THREADS + tid; i < nq; i += P) {
+  for (int i = i_first; i < nq; i += P) {
     float d, a0, a1, a2, b0 = 0.f, b1 = 0.f, b2 = 0.f;
     int j;
     if (rec) {  // (uniform) behind a grid sweep of the device loop: query, match and distance in one 32-byte record
-      const float4 r0 = rec[2 * (size_t)i], r1 = rec[2 * (size_t)i + 1];
+      const float4 r0 = nx0, r1 = nx1;
+      if (i + P < nq) {
+        nx0 = rec[2 * (size_t)(i + P)];
+        nx1 = rec[2 * (size_t)(i + P) + 1];
+      }
       a0 = r0.x, a1 = r0.y, a2 = r0.z, d = r0.w;
       b0 = r1.x, b1 = r1.y, b2 = r1.z, j = __float_as_int(r1.w);
     } else {
