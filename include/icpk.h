@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define ICPK_VERSION_STRING "icpk 0.2.0 (gfx950)"
+#define ICPK_VERSION_STRING "icpk 0.3.0 (gfx950)"
 
 /* ---- status codes -------------------------------------------------------- */
 #define ICPK_OK 0
